@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Headline benchmark: QPS of single-query cosine top-10 over 10M x 768 fp32 rows held in HBM.
+
+  python bench.py --gpus 1 --steps 100 --warmup 10
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one query scored against every stored row, exact top-10 returned (ids + scores) in
+device memory.  With N > 1 the 10M rows are row-sharded over the N ranks (strong scaling): each
+rank scans its shard, one RCCL all-gather exchanges the per-rank top-10 records, every rank
+merges them.  Inputs (table and queries) are resident in HBM before the timed region.
+
+Prints ONE JSON line (rank 0) with the throughput, the roofline of the dominant kernel (the scan:
+algorithmic bytes = rows_per_gpu * dim * 4 per launch over its HIP-event duration inside the
+timed region, against 8 TB/s HBM), and a CPU baseline (the numpy/BLAS port of the same search,
+timed on this host on a bounded sample of the same workload and scaled by rows).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from vectordb_amd import _lib                      # noqa: E402
+from vectordb_amd.engine import Engine             # noqa: E402
+from vectordb_amd.sharded import ShardedSearcher, gpu_backend, shard_range  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0
+DTYPES = {"f32": (_lib.F32, 4), "bf16": (_lib.BF16, 2), "f16": (_lib.F16, 2)}
+METRICS = {"cosine": _lib.METRIC_COSINE, "ip": _lib.METRIC_IP, "l2": _lib.METRIC_L2}
+
+
+def cpu_baseline(rows_total: int, dim: int, k: int, metric_name: str, budget_s: float):
+    """Times the oracle's BLAS path (X @ q, argpartition, canonical re-score) on a sample of the
+    workload's shape and scales QPS by sample_rows / rows_total."""
+    from oracle import oracle as O                  # checker/baseline only, never the product path
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = int(os.environ.get("OMP_NUM_THREADS", "1"))
+    metric = {"cosine": O.COSINE, "ip": O.IP, "l2": O.L2}[metric_name]
+    sample_rows = min(rows_total, 400_000)
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((sample_rows, dim), dtype=np.float32)
+    if metric == O.COSINE:
+        x /= np.linalg.norm(x, axis=1, keepdims=True)       # timing data only
+    ids = np.arange(sample_rows, dtype=np.int64)
+    n2 = (x * x).sum(axis=1) if metric == O.L2 else None
+    q = rng.standard_normal((256, dim), dtype=np.float32)
+    O.fast_search(x, ids, q[:1], k, metric, n2=n2)           # warm-up
+    done, t0 = 0, time.perf_counter()
+    while True:
+        O.fast_search(x, ids, q[done % 256:done % 256 + 1], k, metric, n2=n2)
+        done += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or done >= 2000:
+            break
+    qps_sample = done / el
+    return {
+        "value": qps_sample * sample_rows / rows_total,
+        "unit": "QPS",
+        "cores": int(threads),
+        "kind": "port",
+        "sample": "%d queries in %.1f s on %d x %d fp32 rows (numpy %s sgemv + argpartition + fp64 re-score of "
+                  "k+54 candidates), QPS scaled by %d/%d rows" % (done, el, sample_rows, dim, np.__version__,
+                                                                  sample_rows, rows_total),
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--rows", type=int, default=10_000_000)
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--nq", type=int, default=1, help="queries per step")
+    ap.add_argument("--metric", default="cosine", choices=sorted(METRICS))
+    ap.add_argument("--dtype", default="f32", choices=sorted(DTYPES))
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="0 disables the CPU baseline")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU path exists)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    eng = Engine(device=local_rank)
+    dt, esz = DTYPES[args.dtype]
+    metric = METRICS[args.metric]
+    first, last = shard_range(args.rows, world, rank)
+    n_local = last - first
+    table = "bench"
+    eng.create_table(table, args.dim, metric, dt)
+    eng.reserve(table, n_local)
+    t_fill = time.perf_counter()
+    eng.insert_synthetic(table, n_local, seed=0, first_row=first)
+    t_fill = time.perf_counter() - t_fill
+
+    total = args.steps + args.warmup
+    queries = torch.empty((total * args.nq, args.dim), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream()
+    eng.synth_fill_dev(queries.data_ptr(), total * args.nq, args.dim, seed=1, first_row=0, stream=stream.cuda_stream)
+    local_search, merge = gpu_backend(eng, table, args.nq, args.k, metric)
+    searcher = ShardedSearcher(args.nq, args.k, dev, local_search, merge)
+
+    def step(i: int):
+        return searcher.search(queries[i * args.nq:(i + 1) * args.nq])
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    eng.prof_read()
+    eng.prof_enable(True)
+    t0 = time.perf_counter()
+    for i in range(args.warmup, total):
+        out = step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    eng.prof_enable(False)
+    scan_ms, scan_launches = eng.prof_read()
+    last_ids = out.ids.cpu().numpy().copy()
+    last_scores = out.scores.cpu().numpy().copy()
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    queries_done, fallbacks = eng.stats()
+
+    if rank == 0:
+        qps = args.steps * args.nq / elapsed
+        bytes_per_launch = n_local * args.dim * esz + (n_local * 4 if args.metric == "l2" else 0)
+        avg_scan_s = (scan_ms / max(1, scan_launches)) / 1e3
+        achieved = bytes_per_launch / avg_scan_s / 1e9 if avg_scan_s > 0 else 0.0
+        line = {
+            "metric": "QPS top-%d %s, %dx%d %s, single query" % (args.k, args.metric, args.rows, args.dim, args.dtype)
+                      if args.nq == 1 else
+                      "QPS top-%d %s, %dx%d %s, batch %d" % (args.k, args.metric, args.rows, args.dim, args.dtype, args.nq),
+            "value": qps,
+            "unit": "QPS",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32" if args.dtype == "f32" else args.dtype + " rows, f32 accumulate",
+            "data": "synthetic (counter-hash ~N(0,1) embeddings generated on device, seed 0; queries seed 1)",
+            "config": {
+                "workload": "%dx%d %s %s top-%d, nq=%d per step, rows sharded over %d GPU(s), exact ids+scores"
+                            % (args.rows, args.dim, args.dtype, args.metric, args.k, args.nq, world),
+                "rows_per_gpu": n_local,
+                "parallelism": "row-shard x%d + RCCL all-gather of top-k records" % world if world > 1 else "single GPU",
+                "table_fill_s": round(t_fill, 2),
+                "exact_fallbacks": fallbacks,
+                "queries_counted": queries_done,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "scan_kernel",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "bytes_per_launch": bytes_per_launch,
+                "avg_launch_ms": avg_scan_s * 1e3,
+                "launches_timed": scan_launches,
+            },
+            "sample_result": {"ids": [int(x) for x in last_ids[0][:3]], "scores": [float(x) for x in last_scores[0][:3]]},
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            line["cpu_baseline"] = cpu_baseline(args.rows, args.dim, args.k, args.metric, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,149 @@
+/*
+ * vdb.h -- C ABI of the MI355X brute-force similarity engine (libvdb.so).
+ *
+ * The library stands where the reference reaches its vector engine: the seven
+ * methods /root/reference/app.py calls on a pymilvus `Milvus` object
+ * (connect, has_table, create_table, create_index, delete_table, insert,
+ * search_vectors).  Each entry point below names the reference call it replaces.
+ *
+ * Conventions
+ *   - every function returns VDB_OK (0) on success, matching the reference's
+ *     `status.code == 0` test (app.py:243), or a negative VDB_E* code;
+ *     vdb_last_error() gives a thread-local message for the last failure
+ *     (the reference prints `status.message`, app.py:245);
+ *   - plain pointers and sizes only; the caller allocates every output;
+ *   - host entry points take host pointers; `_dev` entry points take device
+ *     pointers valid on the library's device and a HIP stream handle
+ *     (a `hipStream_t` passed as `void*`, NULL = the default stream), enqueue
+ *     their work on that stream and return without synchronising;
+ *   - thread safety: any number of concurrent searches; inserts on a table are
+ *     serialised and exclude searches on that table while rows are added
+ *     (the reference serves each HTTP request on its own thread against one
+ *     process-global engine handle with no locking: app.py:11-12,186-190);
+ *   - there is no CPU fallback: without a usable GPU vdb_init fails.
+ */
+#ifndef VDB_H
+#define VDB_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* return codes */
+#define VDB_OK            0
+#define VDB_EINVAL      (-1)   /* bad argument */
+#define VDB_ENOTFOUND   (-2)   /* no such table */
+#define VDB_EEXISTS     (-3)   /* table already exists */
+#define VDB_ENOGPU      (-4)   /* no usable HIP device / runtime failure at init */
+#define VDB_EHIP        (-5)   /* a HIP call failed */
+#define VDB_ENOMEM      (-6)   /* HBM budget (gpu_resource_config.cache_capacity) or allocation exceeded */
+#define VDB_ESTATE      (-7)   /* library not initialised / already shut down */
+
+/* metric: the reference fixes MetricType.IP per table (app.py:22,141); L2 and COSINE are additions */
+#define VDB_METRIC_L2     1    /* squared Euclidean distance, smaller is better */
+#define VDB_METRIC_IP     2    /* inner product, larger is better */
+#define VDB_METRIC_COSINE 3    /* rows L2-normalised on insert, query on search, then IP */
+
+/* storage dtype of a table's rows in HBM */
+#define VDB_F32   0
+#define VDB_BF16  1
+#define VDB_F16   2
+
+/* index types accepted (and ignored: every search is an exhaustive scan) by vdb_create_index;
+ * the reference asks for IndexType.IVFLAT, nlist 2048 (app.py:145-149) */
+#define VDB_INDEX_FLAT    1
+#define VDB_INDEX_IVFLAT  2
+
+#define VDB_MAX_TOPK   1024   /* largest k accepted by the search entry points */
+
+/* ---- lifetime: replaces Milvus() + connect(host, port) (app.py:171-182) ---------------- */
+/* Binds the calling process to HIP device `device` (ordinal in the process's visible set).
+ * Calling it again with the same device is a no-op. */
+int vdb_init(int device);
+int vdb_shutdown(void);
+/* Knobs of /root/reference/server_config.yaml, forwarded by the host shim after it has read
+ * that file: "use_blas_threshold" (:36, batch size from which the MFMA GEMM path is used),
+ * "cache_capacity_gb" (:42, HBM budget for all tables, 0 = unlimited),
+ * "insert_buffer_size_gb" (:19, pinned host staging for host inserts). */
+int vdb_set_option(const char* key, double value);
+const char* vdb_last_error(void);
+
+/* ---- table lifecycle ---------------------------------------------------------------------- */
+/* replaces create_table({'table_name','dimension','index_file_size','metric_type'}) (app.py:137-143) */
+int vdb_create_table(const char* name, int64_t dim, int metric, int dtype);
+/* replaces has_table(name) -> (status, bool) (app.py:120) */
+int vdb_has_table(const char* name, int* out_exists);
+/* replaces delete_table(name) (app.py:242) */
+int vdb_drop_table(const char* name);
+/* replaces create_index(name, {'index_type','nlist'}) (app.py:145-149): validates and returns */
+int vdb_create_index(const char* name, int index_type, int nlist);
+/* row count of a table (pymilvus get_table_row_count; not called by app.py, used by tests/bench) */
+int vdb_count(const char* name, int64_t* out_rows);
+/* grow the table's capacity to at least `rows` without changing its contents */
+int vdb_reserve(const char* name, int64_t rows);
+/* describe a table: any out pointer may be NULL */
+int vdb_table_info(const char* name, int64_t* dim, int* metric, int* dtype,
+                   int64_t* rows, int64_t* capacity, int64_t* row_stride_bytes);
+
+/* ---- append: replaces insert(table, records=[vec], ids=[id]) (app.py:315-325) ------------- */
+/* rows: [n, dim] row-major fp32 on the host; ids: [n] caller-supplied signed 64-bit ids.
+ * COSINE tables normalise each row on the device while appending. */
+int vdb_insert(const char* name, int64_t n, const float* rows, const int64_t* ids);
+/* same with rows/ids already in device memory */
+int vdb_insert_dev(const char* name, int64_t n, const float* rows_dev, const int64_t* ids_dev,
+                   void* stream);
+/* append n synthetic rows generated on the device: element (row, col) of the raw fp32 row is a
+ * pure function of (seed, first_row + i, col); ids are first_row + i.  The ingestion-side
+ * counterpart of /root/reference/createVector.py:6-8 for sizes that cannot pass through HTTP. */
+int vdb_insert_synthetic(const char* name, int64_t n, uint64_t seed, int64_t first_row);
+/* fill a caller-owned device buffer [n, dim] fp32 with the same generator (queries, tests) */
+int vdb_synth_fill_dev(float* out_dev, int64_t n, int64_t dim, uint64_t seed, int64_t first_row,
+                       void* stream);
+/* copy stored rows [first, first+n) back to the host as fp32 (tests and snapshots);
+ * out_rows [n, dim], out_ids [n]; either may be NULL */
+int vdb_fetch_rows(const char* name, int64_t first, int64_t n, float* out_rows, int64_t* out_ids);
+
+/* ---- search: replaces search_vectors(table_name, query_records, top_k, nprobe) (app.py:384-391)
+ * queries: [nq, dim] fp32.  Outputs, per query q: out_counts[q] = min(k, rows) hits, best first,
+ * ties ordered by id ascending; out_ids[q*k + i], out_scores[q*k + i]; unused slots hold id -1.
+ * Scores: IP / COSINE similarity (larger first) or squared L2 distance (smaller first).
+ * nprobe of the reference call has no counterpart: the scan is exhaustive. */
+int vdb_search(const char* name, int64_t nq, const float* queries, int k,
+               int64_t* out_ids, float* out_scores, int32_t* out_counts);
+int vdb_search_dev(const char* name, int64_t nq, const float* queries_dev, int k,
+                   int64_t* out_ids_dev, float* out_scores_dev, int32_t* out_counts_dev,
+                   void* stream);
+
+/* ---- row-sharded tables: merge of per-shard results (no counterpart in the reference, which
+ * talks to one engine: server_config.yaml:8 deploy_mode single) -------------------------------
+ * in_*: [nparts, nq, k] as produced by vdb_search_dev on each shard and gathered by the host
+ * side (RCCL all-gather); writes the global top-k in the same format. */
+int vdb_merge_topk_dev(int nparts, int64_t nq, int k, int metric,
+                       const int64_t* in_ids_dev, const float* in_scores_dev,
+                       const int32_t* in_counts_dev,
+                       int64_t* out_ids_dev, float* out_scores_dev, int32_t* out_counts_dev,
+                       void* stream);
+
+/* Per-rank result record for one collective: ids [nq*k] int64 | scores [nq*k] fp32 | counts [nq]
+ * int32, padded to a multiple of 16 bytes.  A rank points vdb_search_dev's three outputs into its
+ * record, the records are all-gathered back to back, and vdb_merge_records_dev merges them. */
+int64_t vdb_record_bytes(int64_t nq, int k);
+int vdb_merge_records_dev(int nparts, int64_t nq, int k, int metric, const void* records_dev,
+                          int64_t* out_ids_dev, float* out_scores_dev, int32_t* out_counts_dev,
+                          void* stream);
+
+/* ---- measurement hooks (bench.py) ------------------------------------------------------------ */
+/* When enabled, every scan kernel launch is bracketed by HIP events on its stream. */
+int vdb_prof_enable(int on);
+/* Synchronises the recorded events; returns summed scan-kernel milliseconds and launch count
+ * since the last call, and resets both. */
+int vdb_prof_read(double* scan_ms, int64_t* scan_launches);
+/* counters since init: searches (queries), queries that needed the exact second pass */
+int vdb_stats(int64_t* queries, int64_t* exact_fallbacks);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VDB_H */

@@ -1,0 +1,96 @@
+"""CPU tests of the boundary: libvdb.so loads, exports every symbol include/vdb.h declares,
+refuses to run without a GPU, and the client shim reports failures the way its caller expects."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from vectordb_amd import _lib
+from vectordb_amd.config import EngineConfig, load_config, parse_config
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "vdb.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vdb_[a-z_0-9]+)\s*\(", text)))
+
+
+def _gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), "libvdb.so does not export %s" % name
+    assert sorted(_lib.SIGNATURES) == declared
+
+
+def test_constants_match_header():
+    text = open(os.path.join(ROOT, "include", "vdb.h")).read()
+    defs = {m.group(1): int(m.group(2).strip("()")) for m in
+            re.finditer(r"#define\s+(VDB_[A-Z0-9_]+)\s+(\(?-?\d+\)?)", text)}
+    assert defs["VDB_OK"] == _lib.OK
+    assert (defs["VDB_METRIC_L2"], defs["VDB_METRIC_IP"], defs["VDB_METRIC_COSINE"]) == \
+        (_lib.METRIC_L2, _lib.METRIC_IP, _lib.METRIC_COSINE)
+    assert (defs["VDB_F32"], defs["VDB_BF16"], defs["VDB_F16"]) == (_lib.F32, _lib.BF16, _lib.F16)
+    assert defs["VDB_ENOGPU"] == _lib.ENOGPU and defs["VDB_MAX_TOPK"] == _lib.MAX_TOPK
+    from oracle import oracle as O
+    assert (O.L2, O.IP, O.COSINE, O.F32, O.BF16, O.F16) == (1, 2, 3, 0, 1, 2)
+
+
+@pytest.mark.skipif(_gpu(), reason="checks the no-GPU failure path")
+def test_no_gpu_means_failure_not_fallback():
+    lib = _lib.load()
+    assert lib.vdb_init(0) == _lib.ENOGPU
+    assert "HIP device" in _lib.last_error()
+    # nothing works before a successful init
+    out = ctypes.c_int(0)
+    assert lib.vdb_has_table(b"x", ctypes.byref(out)) == _lib.ESTATE
+    assert lib.vdb_create_table(b"x", 8, _lib.METRIC_IP, _lib.F32) == _lib.ESTATE
+    from milvus import Milvus
+    st = Milvus().connect(host="127.0.0.1", port="19530")
+    assert not st.OK() and st.code == _lib.ENOGPU        # app.py:178-182 exits on this
+
+
+def test_shim_surface_matches_reference_imports():
+    import milvus
+    from milvus import IndexType, MetricType, Milvus     # app.py:3
+    assert MetricType.IP and IndexType.IVFLAT            # app.py:22,146
+    m = Milvus()
+    for meth in ("connect", "has_table", "create_table", "create_index", "delete_table", "insert",
+                 "search_vectors"):
+        assert callable(getattr(m, meth))
+    # not connected: every call answers with a failing status instead of raising
+    st, ok = m.has_table("nope")
+    assert not st.OK() and ok is False
+    assert not m.create_table({"table_name": "a", "dimension": 8}).OK()
+    st, res = m.search_vectors(table_name="a", query_records=[[0.0] * 8], top_k=10, nprobe=10)
+    assert not st.OK() and res == []
+    assert m.delete_table("a").code != 0
+
+
+def test_config_reads_reference_style_file(tmp_path):
+    p = tmp_path / "server_config.yaml"
+    p.write_text(
+        "version: 0.1\n"
+        "db_config:\n  primary_path: /tmp/vdb\n  insert_buffer_size: 2\n  preload_table: a, b\n"
+        "engine_config:\n  use_blas_threshold: 32\n  gpu_search_threshold: 1000\n"
+        "gpu_resource_config:\n  enable: true\n  cache_capacity: 64\n  search_resources:\n    - gpu0\n    - gpu3\n")
+    cfg = load_config(str(p))
+    assert cfg.use_blas_threshold == 32 and cfg.cache_capacity_gb == 64.0
+    assert cfg.search_resources == [0, 3] and cfg.device_for_rank(1) == 3 and cfg.device_for_rank(2) == 0
+    assert cfg.primary_path == "/tmp/vdb" and cfg.preload_table == ["a", "b"]
+    assert cfg.insert_buffer_size_gb == 2.0
+    with pytest.raises(ValueError):
+        parse_config({"gpu_resource_config": {"search_resources": ["cpu0"]}})
+    assert isinstance(parse_config(None), EngineConfig)

@@ -1,0 +1,341 @@
+"""GPU parity tests: every call goes through the C ABI of libvdb.so and is compared with the
+numpy oracle on the same inputs.  Bar: ids identical, scores bit-identical."""
+import json
+import os
+import threading
+
+import numpy as np
+import pytest
+
+import cases
+from oracle import oracle as O
+from vectordb_amd import _lib
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _check(engine, name, stored, ids, queries, k, metric):
+    got_ids, got_sc, got_cnt = engine.search(name, queries, k)
+    want = O.search(stored, ids, queries, k, metric)
+    for qi, (wi, ws) in enumerate(want):
+        c = int(got_cnt[qi])
+        assert c == len(wi), "query %d: count %d != %d" % (qi, c, len(wi))
+        assert np.array_equal(got_ids[qi, :c], wi), "query %d ids\n got %s\nwant %s" % (qi, got_ids[qi, :c], wi)
+        assert np.array_equal(got_sc[qi, :c].view(np.uint32), ws.view(np.uint32)), \
+            "query %d scores\n got %s\nwant %s" % (qi, got_sc[qi, :c], ws)
+        assert np.all(got_ids[qi, c:] == -1)
+
+
+def _load(engine, name, rows, ids, metric, dtype):
+    engine.create_table(name, rows.shape[1], metric, dtype)
+    engine.insert(name, rows, ids)
+    assert engine.count(name) == rows.shape[0]
+    return O.prepare_store(rows, metric, dtype)
+
+
+# ------------------------------------------------------------------------------- store
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("metric", ["ip", "cosine"])
+def test_stored_rows_match_oracle_bitwise(engine, table_name, metric, dtype):
+    # many rows of several lengths: covers the device's fp64 sqrt and division (normalisation)
+    d = 37
+    rows = cases.make_rows("synth", 31, 20000, d)
+    rows[5] = 0.0
+    ids = cases.make_ids("hash", 31, rows.shape[0])
+    stored = _load(engine, table_name, rows, ids, cases.METRICS[metric], cases.DTYPES[dtype])
+    got_rows, got_ids = engine.fetch_rows(table_name, 0, rows.shape[0])
+    assert np.array_equal(got_ids, ids)
+    assert np.array_equal(got_rows.view(np.uint32), stored.view(np.uint32))
+
+
+def test_synthetic_rows_match_oracle_bitwise(engine, table_name):
+    import torch
+    engine.create_table(table_name, 96, _lib.METRIC_IP, _lib.F32)
+    engine.insert_synthetic(table_name, 3000, seed=5, first_row=0)
+    engine.insert_synthetic(table_name, 500, seed=5, first_row=3000)
+    got, ids = engine.fetch_rows(table_name, 0, 3500)
+    want = O.synth_rows(5, 0, 3500, 96)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(ids, np.arange(3500))
+    buf = torch.empty((70, 33), dtype=torch.float32, device="cuda")
+    engine.synth_fill_dev(buf.data_ptr(), 70, 33, seed=9, first_row=11,
+                          stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(buf.cpu().numpy().view(np.uint32), O.synth_rows(9, 11, 70, 33).view(np.uint32))
+
+
+def test_synthetic_cosine_table_is_normalised_like_the_oracle(engine, table_name):
+    engine.create_table(table_name, 768, _lib.METRIC_COSINE, _lib.F32)
+    engine.insert_synthetic(table_name, 2000, seed=0, first_row=100)
+    got, ids = engine.fetch_rows(table_name, 0, 2000)
+    want = O.normalize_rows(O.synth_rows(0, 100, 2000, 768))
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert ids[0] == 100 and ids[-1] == 2099
+
+
+# ------------------------------------------------------------------------------- search
+@pytest.mark.parametrize("d", [1, 8, 100, 128, 384, 768, 1000, 1536, 2500])
+@pytest.mark.parametrize("metric", ["ip", "cosine", "l2"])
+def test_search_parity_fp32_dims(engine, table_name, metric, d):
+    n = 3000
+    rows = cases.make_rows("synth", d, n, d)
+    ids = cases.make_ids("hash", d, n)
+    q = cases.make_queries("synth", d, 3, d, rows)
+    m = cases.METRICS[metric]
+    stored = _load(engine, table_name, rows, ids, m, O.F32)
+    _check(engine, table_name, stored, ids, q, 10, m)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("d", [8, 128, 520, 768, 4100])
+@pytest.mark.parametrize("metric", ["ip", "cosine", "l2"])
+def test_search_parity_16bit(engine, table_name, metric, d, dtype):
+    n = 2000
+    rows = cases.make_rows("synth", d + 1, n, d)
+    ids = cases.make_ids("index", 0, n)
+    q = cases.make_queries("synth", d + 1, 2, d, rows)
+    m = cases.METRICS[metric]
+    stored = _load(engine, table_name, rows, ids, m, cases.DTYPES[dtype])
+    _check(engine, table_name, stored, ids, q, 10, m)
+
+
+@pytest.mark.parametrize("n", [1, 2, 9, 31, 32, 33, 63, 64, 65, 1000, 4097])
+@pytest.mark.parametrize("k", [1, 10, 100])
+def test_search_parity_sizes(engine, table_name, n, k):
+    d = 48
+    rows = cases.make_rows("synth", n, n, d)
+    ids = cases.make_ids("hash", n, n)
+    q = cases.make_queries("synth", n, 2, d, rows)
+    stored = _load(engine, table_name, rows, ids, O.COSINE, O.F32)
+    _check(engine, table_name, stored, ids, q, k, O.COSINE)
+
+
+def test_search_parity_config1_shape(engine, table_name):
+    # 10k x 384 U[0,1) vectors as createVector.py draws them, hashed ids, cosine top-10
+    rows = cases.make_rows("uniform", 0, 10000, 384)
+    ids = np.array([O.hash_vector(r.tolist()) for r in rows[:200]] + list(cases.make_ids("hash", 0, 10000 - 200)),
+                   dtype=np.int64)
+    q = cases.make_queries("uniform", 0, 20, 384, rows)
+    stored = _load(engine, table_name, rows, ids, O.COSINE, O.F32)
+    _check(engine, table_name, stored, ids, q, 10, O.COSINE)
+
+
+def test_search_parity_large_k(engine, table_name):
+    rows = cases.make_rows("synth", 77, 6000, 64)
+    ids = cases.make_ids("hash", 77, 6000)
+    q = cases.make_queries("synth", 77, 2, 64, rows)
+    stored = _load(engine, table_name, rows, ids, O.IP, O.F32)
+    for k in (257, 1024):
+        _check(engine, table_name, stored, ids, q, k, O.IP)
+
+
+@pytest.mark.parametrize("case", cases.GOLDEN_CASES, ids=lambda c: "-".join(map(str, c)))
+def test_golden_fixtures(engine, table_name, case):
+    golden = json.load(open(os.path.join(HERE, "golden", "search_golden.json")))
+    g = next(x for x in golden if tuple(x["case"]) == case)
+    rk, ik, seed, n, d, metric, dtype, k, nq = case
+    rows = cases.make_rows(rk, seed, n, d)
+    ids = cases.make_ids(ik, seed, n)
+    q = cases.make_queries(rk, seed, nq, d, rows)
+    _load(engine, table_name, rows, ids, cases.METRICS[metric], cases.DTYPES[dtype])
+    got_ids, got_sc, got_cnt = engine.search(table_name, q, k)
+    for qi in range(nq):
+        c = int(got_cnt[qi])
+        assert [int(x) for x in got_ids[qi, :c]] == g["ids"][qi]
+        assert [int(x) for x in got_sc[qi, :c].view(np.uint32)] == g["score_bits"][qi]
+
+
+# ------------------------------------------------------------------------------- ties
+@pytest.mark.parametrize("metric", ["ip", "l2", "cosine"])
+@pytest.mark.parametrize("kind", ["ties", "dups"])
+def test_ties_are_ordered_by_signed_id(engine, table_name, kind, metric):
+    n, d = 5000, 16
+    rows = cases.make_rows(kind, 13, n, d)
+    ids = cases.make_ids("hash", 13, n)
+    q = cases.make_queries(kind, 13, 3, d, rows)
+    m = cases.METRICS[metric]
+    stored = _load(engine, table_name, rows, ids, m, O.F32)
+    before = engine.stats()[1]
+    _check(engine, table_name, stored, ids, q, 10, m)
+    if kind == "dups":
+        # 5000 equal scores cannot be certified from 32 candidates: the exact pass must have run
+        assert engine.stats()[1] > before
+
+
+def test_duplicate_ids_and_extreme_ids(engine, table_name):
+    d = 24
+    rows = cases.make_rows("synth", 3, 400, d)
+    ids = cases.make_ids("hash", 3, 400)
+    ids[:4] = [np.iinfo(np.int64).max, np.iinfo(np.int64).min, -1, 0]
+    rows[10] = rows[11]
+    ids[10] = ids[11]                     # the same vector under the same id twice
+    q = np.concatenate([rows[10:11], rows[0:1], rows[1:2]])
+    stored = _load(engine, table_name, rows, ids, O.IP, O.F32)
+    _check(engine, table_name, stored, ids, q, 10, O.IP)
+
+
+# ------------------------------------------------------------------------------- edges
+def test_empty_table_and_zero_queries(engine, table_name):
+    engine.create_table(table_name, 8, _lib.METRIC_IP, _lib.F32)
+    ids, sc, cnt = engine.search(table_name, np.zeros((2, 8), np.float32), 10)
+    assert list(cnt) == [0, 0] and np.all(ids == -1)
+    ids, sc, cnt = engine.search(table_name, np.zeros((0, 8), np.float32), 10)
+    assert ids.shape == (0, 10)
+    engine.insert(table_name, np.zeros((0, 8), np.float32), np.zeros((0,), np.int64))
+    assert engine.count(table_name) == 0
+
+
+def test_error_codes(engine, table_name):
+    from vectordb_amd import VdbError
+    engine.create_table(table_name, 8, _lib.METRIC_IP, _lib.F32)
+    with pytest.raises(VdbError) as e:
+        engine.create_table(table_name, 8, _lib.METRIC_IP, _lib.F32)
+    assert e.value.code == _lib.EEXISTS
+    with pytest.raises(VdbError) as e:
+        engine.search("missing", np.zeros((1, 8), np.float32), 10)
+    assert e.value.code == _lib.ENOTFOUND
+    with pytest.raises(VdbError) as e:
+        engine.search(table_name, np.zeros((1, 8), np.float32), 0)
+    assert e.value.code == _lib.EINVAL
+    with pytest.raises(VdbError) as e:
+        engine.search(table_name, np.zeros((1, 8), np.float32), _lib.MAX_TOPK + 1)
+    assert e.value.code == _lib.EINVAL
+    with pytest.raises(VdbError) as e:
+        engine.create_table("bad", 0, _lib.METRIC_IP, _lib.F32)
+    assert e.value.code == _lib.EINVAL
+    with pytest.raises(VdbError) as e:
+        engine.drop_table("missing")
+    assert e.value.code == _lib.ENOTFOUND
+    engine.create_index(table_name)      # accepted, nothing to build
+
+
+def test_append_grows_and_stays_searchable(engine, table_name):
+    d = 40
+    rows = cases.make_rows("synth", 55, 5000, d)
+    ids = cases.make_ids("hash", 55, 5000)
+    q = cases.make_queries("synth", 55, 2, d, rows)
+    engine.create_table(table_name, d, _lib.METRIC_COSINE, _lib.F32)
+    stored = O.prepare_store(rows, O.COSINE)
+    done = 0
+    for step in (1, 1, 1, 500, 700, 2, 3795):      # one row per call (app.py:325), then bulk
+        engine.insert(table_name, rows[done:done + step], ids[done:done + step])
+        done += step
+        assert engine.count(table_name) == done
+        _check(engine, table_name, stored[:done], ids[:done], q, 10, O.COSINE)
+    assert done == 5000 and engine.table_info(table_name)["capacity"] >= 5000
+
+
+def test_concurrent_searches_and_inserts(engine, table_name):
+    d = 32
+    rows = cases.make_rows("synth", 8, 4000, d)
+    ids = cases.make_ids("index", 0, 4000)
+    q = cases.make_queries("synth", 8, 1, d, rows)
+    engine.create_table(table_name, d, _lib.METRIC_IP, _lib.F32)
+    engine.insert(table_name, rows[:1000], ids[:1000])
+    stored = O.prepare_store(rows, O.IP)
+    errors = []
+
+    def searcher():
+        try:
+            for _ in range(40):
+                gi, gs, gc = engine.search(table_name, q, 5)
+                n = engine.count(table_name)
+                # the answer must be the exact top-5 of some prefix between the two counts
+                sc = O.scores(stored, O.prepare_query(q[0], O.IP), O.IP)
+                assert gc[0] == 5
+                assert np.array_equal(gs[0].view(np.uint32), sc[gi[0]].view(np.uint32))
+                assert np.all(gi[0] < n)
+        except Exception as exc:      # noqa: BLE001
+            errors.append(exc)
+
+    def inserter():
+        try:
+            for i in range(1000, 4000, 100):
+                engine.insert(table_name, rows[i:i + 100], ids[i:i + 100])
+        except Exception as exc:      # noqa: BLE001
+            errors.append(exc)
+
+    ts = [threading.Thread(target=searcher) for _ in range(4)] + [threading.Thread(target=inserter)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    _check(engine, table_name, stored, ids, q, 10, O.IP)
+
+
+# ------------------------------------------------------------------------------- device entry
+def test_search_dev_and_shard_merge(engine):
+    """Row-sharded search on one device: S logical shards, per-shard vdb_search_dev, then
+    vdb_merge_topk_dev -- the same data path the multi-GPU host side drives over RCCL."""
+    import torch
+    d, n, k, nq, S = 64, 6000, 10, 4, 3
+    rows = cases.make_rows("ties", 4, n, d)
+    ids = cases.make_ids("hash", 4, n)
+    q = cases.make_queries("ties", 4, nq, d, rows)
+    stored = O.prepare_store(rows, O.L2)
+    st = torch.cuda.current_stream().cuda_stream
+    qd = torch.from_numpy(q).cuda()
+    p_ids = torch.empty((S, nq, k), dtype=torch.int64, device="cuda")
+    p_sc = torch.empty((S, nq, k), dtype=torch.float32, device="cuda")
+    p_cnt = torch.empty((S, nq), dtype=torch.int32, device="cuda")
+    names = []
+    try:
+        for s in range(S):
+            name = "shard%d" % s
+            names.append(name)
+            sl = slice(s * n // S, (s + 1) * n // S)
+            engine.create_table(name, d, _lib.METRIC_L2, _lib.F32)
+            engine.insert(name, rows[sl], ids[sl])
+            engine.search_dev(name, nq, qd.data_ptr(), k, p_ids[s].data_ptr(), p_sc[s].data_ptr(),
+                              p_cnt[s].data_ptr(), st)
+        o_ids = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+        o_sc = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+        o_cnt = torch.empty((nq,), dtype=torch.int32, device="cuda")
+        engine.merge_topk_dev(S, nq, k, _lib.METRIC_L2, p_ids.data_ptr(), p_sc.data_ptr(), p_cnt.data_ptr(),
+                              o_ids.data_ptr(), o_sc.data_ptr(), o_cnt.data_ptr(), st)
+        torch.cuda.synchronize()
+        want = O.search(stored, ids, q, k, O.L2)
+        for qi, (wi, ws) in enumerate(want):
+            assert int(o_cnt[qi]) == k
+            assert np.array_equal(o_ids[qi].cpu().numpy(), wi)
+            assert np.array_equal(o_sc[qi].cpu().numpy().view(np.uint32), ws.view(np.uint32))
+    finally:
+        for name in names:
+            if engine.has_table(name):
+                engine.drop_table(name)
+
+
+# ------------------------------------------------------------------------------- full size
+def test_one_million_rows_properties(engine, table_name):
+    """BASELINE config 2 (1M x 768 fp32 cosine top-10) through size-independent properties:
+    returned scores are the canonical scores of the returned rows (rows regenerated on the
+    host), order is (score, id), a planted duplicate of the query comes first with its
+    own score, and no row of a 20k-row sample beats the k-th hit."""
+    import torch
+    n, d, k = 1_000_000, 768, 10
+    engine.create_table(table_name, d, _lib.METRIC_COSINE, _lib.F32)
+    engine.insert_synthetic(table_name, n, seed=0, first_row=0)
+    assert engine.count(table_name) == n
+    q = O.synth_rows(1, 0, 3, d)
+    q[2] = O.synth_rows(0, 123456, 1, d)[0]            # equals stored row 123456 before normalisation
+    ids, sc, cnt = engine.search(table_name, q, k)
+    assert list(cnt) == [k] * 3
+    assert ids[2, 0] == 123456
+    for qi in range(3):
+        qp = O.prepare_query(q[qi], O.COSINE)
+        rows = np.stack([O.normalize_rows(O.synth_rows(0, int(r), 1, d))[0] for r in ids[qi]])
+        want = O.scores(rows, qp, O.COSINE)
+        assert np.array_equal(want.view(np.uint32), sc[qi].view(np.uint32))
+        order = np.lexsort((ids[qi], -sc[qi]))
+        assert np.array_equal(order, np.arange(k))
+        sample0 = 400_000 + qi * 20_000
+        sample = O.normalize_rows(O.synth_rows(0, sample0, 20_000, d))
+        ssc = O.scores(sample, qp, O.COSINE)
+        better = np.nonzero(ssc > sc[qi, k - 1])[0] + sample0
+        assert set(better.tolist()) <= set(ids[qi].tolist())
+    # idempotence
+    ids2, sc2, _ = engine.search(table_name, q, k)
+    assert np.array_equal(ids, ids2) and np.array_equal(sc.view(np.uint32), sc2.view(np.uint32))
+    assert engine.stats()[1] >= 0

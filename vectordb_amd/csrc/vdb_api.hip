@@ -1,0 +1,709 @@
+// C-ABI layer: table registry, HBM-resident store with device-side append, search orchestration.
+// See include/vdb.h for the contract of every entry point.
+#include "vdb_internal.h"
+
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <shared_mutex>
+#include <string>
+#include <vector>
+
+namespace vdb {
+
+// ------------------------------------------------------------------------------ error state
+static thread_local std::string tl_error;
+
+static int fail(int code, const std::string& msg) {
+    tl_error = msg;
+    return code;
+}
+
+#define VDB_HIP(expr)                                                                            \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess)                                                                    \
+            return fail(VDB_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e));            \
+    } while (0)
+
+// ------------------------------------------------------------------------------ global state
+struct DevBuf {
+    void*  p = nullptr;
+    size_t cap = 0;
+};
+
+struct Workspace {
+    hipStream_t stream = nullptr;        // own stream for the host entry points
+    hipStream_t last_stream = nullptr;   // stream the last call was enqueued on
+    hipEvent_t  done = nullptr;          // recorded after the last call's work
+    bool        used = false;
+    DevBuf qprep, qinfo, cand_s, cand_t, need_exact;      // search scratch
+    DevBuf q_raw, o_ids, o_scores, o_counts;              // staging of the host entry point
+};
+
+struct Table {
+    std::string name;
+    int64_t dim = 0;
+    int metric = 0, dtype = 0;
+    int m = 0;          // 16-byte units per row
+    int dpad = 0;       // elements per padded row
+    int64_t rows = 0, cap = 0;
+    char*      d_rows = nullptr;
+    long long* d_ids = nullptr;
+    float*     d_n2 = nullptr;
+    float*     d_maxn2 = nullptr;
+    std::shared_mutex mu;
+    bool dropped = false;
+
+    size_t bytes_per_row() const { return (size_t)m * 16 + sizeof(long long) + sizeof(float); }
+};
+
+struct Global {
+    std::mutex mu;                       // registry, workspaces, options
+    bool inited = false;
+    int device = 0;
+    int n_cu = 256;
+    std::map<std::string, std::shared_ptr<Table>> tables;
+    std::vector<std::unique_ptr<Workspace>> free_ws;
+    long long* d_counters = nullptr;
+    // options
+    int use_blas_threshold = 20;
+    double cache_capacity_gb = 0.0;
+    double insert_buffer_gb = 1.0;
+    size_t table_bytes = 0;
+    // host-insert staging (guarded by insert_mu)
+    std::mutex insert_mu;
+    DevBuf stage_rows, stage_ids;
+    hipStream_t insert_stream = nullptr;
+    // profiling
+    std::atomic<int> prof_on{0};
+    std::mutex prof_mu;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
+};
+static Global G;
+
+static int enter() {
+    if (!G.inited) return fail(VDB_ESTATE, "vdb_init has not been called");
+    hipError_t e = hipSetDevice(G.device);
+    if (e != hipSuccess) return fail(VDB_EHIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    return VDB_OK;
+}
+
+static int ensure(DevBuf& b, size_t bytes, hipStream_t busy_on) {
+    if (bytes <= b.cap) return VDB_OK;
+    if (b.p) {
+        if (busy_on) VDB_HIP(hipStreamSynchronize(busy_on));
+        VDB_HIP(hipFree(b.p));
+        b.p = nullptr; b.cap = 0;
+    }
+    size_t want = bytes + bytes / 4;
+    if (want < 4096) want = 4096;
+    VDB_HIP(hipMalloc(&b.p, want));
+    b.cap = want;
+    return VDB_OK;
+}
+
+static std::shared_ptr<Table> find_table(const char* name) {
+    std::lock_guard<std::mutex> lk(G.mu);
+    auto it = G.tables.find(name);
+    return it == G.tables.end() ? nullptr : it->second;
+}
+
+// A workspace may be reused at once by work on the stream it last served (stream order keeps the
+// two uses apart); otherwise only after its last work has completed.
+static int acquire_ws(hipStream_t st, std::unique_ptr<Workspace>& out) {
+    {
+        std::lock_guard<std::mutex> lk(G.mu);
+        int pick = -1;
+        for (size_t i = 0; i < G.free_ws.size(); ++i) {
+            Workspace* w = G.free_ws[i].get();
+            if (!w->used || (st != nullptr && w->last_stream == st)) { pick = (int)i; break; }
+        }
+        if (pick < 0) {
+            for (size_t i = 0; i < G.free_ws.size(); ++i)
+                if (hipEventQuery(G.free_ws[i]->done) == hipSuccess) { pick = (int)i; break; }
+        }
+        if (pick >= 0) {
+            out = std::move(G.free_ws[pick]);
+            G.free_ws.erase(G.free_ws.begin() + pick);
+            return VDB_OK;
+        }
+    }
+    std::unique_ptr<Workspace> w(new Workspace());
+    VDB_HIP(hipStreamCreate(&w->stream));
+    VDB_HIP(hipEventCreateWithFlags(&w->done, hipEventDisableTiming));
+    out = std::move(w);
+    return VDB_OK;
+}
+
+static void release_ws(std::unique_ptr<Workspace>& w, hipStream_t st) {
+    w->used = true;
+    w->last_stream = st;
+    (void)hipEventRecord(w->done, st);
+    std::lock_guard<std::mutex> lk(G.mu);
+    G.free_ws.push_back(std::move(w));
+}
+
+SelGeom sel_geom(int k) {
+    SelGeom g;
+    int margin = k / 8;
+    if (margin < 22) margin = 22;
+    g.K = ((k + margin + 31) / 32) * 32;
+    int need = 2 * g.K > g.K + 64 ? 2 * g.K : g.K + 64;
+    g.C = 64;
+    while (g.C < need) g.C <<= 1;
+    int w = 4096 / g.C;          // W*C*12 bytes of LDS per block stays within 48 KiB
+    if (w > 16) w = 16;
+    if (w < 1) w = 1;
+    g.W = w;
+    return g;
+}
+
+// ------------------------------------------------------------------------------ tiny kernels
+__global__ void fill_empty_kernel(long long* ids, float* scores, int* counts, long long nq, int k, int l2) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nq * k) { ids[i] = -1; scores[i] = l2 ? __builtin_huge_valf() : -__builtin_huge_valf(); }
+    if (i < nq) counts[i] = 0;
+}
+
+// ------------------------------------------------------------------------------ search core
+static int search_core(Table& t, int64_t nq, const float* q_dev, int k, long long* out_ids,
+                       float* out_scores, int* out_counts, hipStream_t st, Workspace& ws) {
+    TableView tv;
+    tv.rows = t.d_rows; tv.ids = t.d_ids; tv.n2 = t.d_n2; tv.max_n2 = t.d_maxn2;
+    tv.n = t.rows; tv.d = (int)t.dim; tv.m = t.m; tv.dt = t.dtype; tv.metric = t.metric;
+    const int l2 = t.metric == VDB_METRIC_L2;
+    if (tv.n == 0) {
+        const long long tot = nq * k > nq ? nq * k : nq;
+        hipLaunchKernelGGL(fill_empty_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st,
+                           out_ids, out_scores, out_counts, (long long)nq, k, l2);
+        VDB_HIP(hipGetLastError());
+        return VDB_OK;
+    }
+    const SelGeom g = sel_geom(k);
+    const int Gx = scan_grid(tv, g, G.n_cu);
+    const int64_t chunk = 256;
+    const int64_t nqc = nq < chunk ? nq : chunk;
+    int rc;
+    if ((rc = ensure(ws.qprep, (size_t)nqc * t.dpad * sizeof(float), ws.last_stream))) return rc;
+    if ((rc = ensure(ws.qinfo, (size_t)nqc * sizeof(QInfo), ws.last_stream))) return rc;
+    if ((rc = ensure(ws.cand_s, (size_t)nqc * Gx * g.K * sizeof(float), ws.last_stream))) return rc;
+    if ((rc = ensure(ws.cand_t, (size_t)nqc * Gx * g.K * sizeof(long long), ws.last_stream))) return rc;
+    if ((rc = ensure(ws.need_exact, (size_t)nqc * sizeof(int), ws.last_stream))) return rc;
+
+    for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
+        const int64_t nqi = nq - q0 < chunk ? nq - q0 : chunk;
+        float* qprep = (float*)ws.qprep.p;
+        QInfo* qinfo = (QInfo*)ws.qinfo.p;
+        float* cs = (float*)ws.cand_s.p;
+        long long* ct = (long long*)ws.cand_t.p;
+        int* ne = (int*)ws.need_exact.p;
+        VDB_HIP(launch_prep_query(q_dev + (size_t)q0 * t.dim, nqi, (int)t.dim, t.dpad, t.metric, qprep, qinfo, st));
+
+        std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+        const bool prof = G.prof_on.load() != 0;
+        if (prof) {
+            std::lock_guard<std::mutex> lk(G.prof_mu);
+            if (!G.prof_pool.empty()) { ev = G.prof_pool.back(); G.prof_pool.pop_back(); }
+        }
+        if (prof && !ev.first) {
+            VDB_HIP(hipEventCreate(&ev.first));
+            VDB_HIP(hipEventCreate(&ev.second));
+        }
+        if (prof) VDB_HIP(hipEventRecord(ev.first, st));
+        VDB_HIP(launch_scan(tv, qprep, nqi, t.dpad, g, Gx, cs, ct, st));
+        if (prof) {
+            VDB_HIP(hipEventRecord(ev.second, st));
+            std::lock_guard<std::mutex> lk(G.prof_mu);
+            G.prof_events.push_back(ev);
+        }
+        VDB_HIP(launch_finalize(tv, qprep, qinfo, nqi, t.dpad, g, Gx, k, cs, ct,
+                                out_ids + (size_t)q0 * k, out_scores + (size_t)q0 * k, out_counts + q0,
+                                ne, G.d_counters, st));
+        VDB_HIP(launch_exact(tv, qprep, nqi, t.dpad, g, Gx, k, cs, ct,
+                             out_ids + (size_t)q0 * k, out_scores + (size_t)q0 * k, out_counts + q0,
+                             ne, G.d_counters, st));
+    }
+    return VDB_OK;
+}
+
+// ------------------------------------------------------------------------------ table storage
+static int table_alloc(Table& t, int64_t new_cap) {
+    // caller holds the table's exclusive lock
+    const size_t need = (size_t)new_cap * t.bytes_per_row();
+    const size_t have = (size_t)t.cap * t.bytes_per_row();
+    {
+        std::lock_guard<std::mutex> lk(G.mu);
+        if (G.cache_capacity_gb > 0.0) {
+            const double budget = G.cache_capacity_gb * 1073741824.0;
+            if ((double)(G.table_bytes - have + need) > budget)
+                return fail(VDB_ENOMEM, "table storage would exceed gpu_resource_config.cache_capacity");
+        }
+    }
+    char* nr = nullptr; long long* ni = nullptr; float* nn = nullptr;
+    hipError_t e = hipMalloc((void**)&nr, (size_t)new_cap * t.m * 16);
+    if (e == hipSuccess) e = hipMalloc((void**)&ni, (size_t)new_cap * sizeof(long long));
+    if (e == hipSuccess) e = hipMalloc((void**)&nn, (size_t)new_cap * sizeof(float));
+    if (e != hipSuccess) {
+        if (nr) (void)hipFree(nr);
+        if (ni) (void)hipFree(ni);
+        if (nn) (void)hipFree(nn);
+        return fail(VDB_ENOMEM, std::string("hipMalloc for table rows: ") + hipGetErrorString(e));
+    }
+    // searches enqueued earlier on caller streams may still read the old buffers
+    VDB_HIP(hipDeviceSynchronize());
+    if (t.rows > 0) {
+        VDB_HIP(hipMemcpy(nr, t.d_rows, (size_t)t.rows * t.m * 16, hipMemcpyDeviceToDevice));
+        VDB_HIP(hipMemcpy(ni, t.d_ids, (size_t)t.rows * sizeof(long long), hipMemcpyDeviceToDevice));
+        VDB_HIP(hipMemcpy(nn, t.d_n2, (size_t)t.rows * sizeof(float), hipMemcpyDeviceToDevice));
+    }
+    if (t.d_rows) (void)hipFree(t.d_rows);
+    if (t.d_ids) (void)hipFree(t.d_ids);
+    if (t.d_n2) (void)hipFree(t.d_n2);
+    t.d_rows = nr; t.d_ids = ni; t.d_n2 = nn;
+    {
+        std::lock_guard<std::mutex> lk(G.mu);
+        G.table_bytes = G.table_bytes - have + need;
+    }
+    t.cap = new_cap;
+    return VDB_OK;
+}
+
+static int table_grow_for(Table& t, int64_t extra) {
+    if (t.rows + extra <= t.cap) return VDB_OK;
+    int64_t nc = t.cap * 2;
+    if (nc < t.rows + extra) nc = t.rows + extra;
+    if (nc < 1024) nc = 1024;
+    return table_alloc(t, nc);
+}
+
+static void table_free(Table& t) {
+    (void)hipDeviceSynchronize();
+    const size_t have = (size_t)t.cap * t.bytes_per_row();
+    if (t.d_rows) (void)hipFree(t.d_rows);
+    if (t.d_ids) (void)hipFree(t.d_ids);
+    if (t.d_n2) (void)hipFree(t.d_n2);
+    if (t.d_maxn2) (void)hipFree(t.d_maxn2);
+    t.d_rows = nullptr; t.d_ids = nullptr; t.d_n2 = nullptr; t.d_maxn2 = nullptr;
+    t.rows = 0; t.cap = 0; t.dropped = true;
+    std::lock_guard<std::mutex> lk(G.mu);
+    G.table_bytes -= have;
+}
+
+}  // namespace vdb
+
+using namespace vdb;
+
+// ================================================================================== C ABI
+extern "C" {
+
+const char* vdb_last_error(void) { return tl_error.c_str(); }
+
+int vdb_init(int device) {
+    std::lock_guard<std::mutex> lk(G.mu);
+    if (G.inited) {
+        if (device == G.device) return VDB_OK;
+        return fail(VDB_ESTATE, "already initialised on another device");
+    }
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(VDB_ENOGPU, std::string("no usable HIP device: ") +
+                                    (e != hipSuccess ? hipGetErrorString(e) : "device count is 0"));
+    if (device < 0 || device >= count) return fail(VDB_EINVAL, "device ordinal out of range");
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return fail(VDB_ENOGPU, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return fail(VDB_ENOGPU, std::string("hipGetDeviceProperties: ") + hipGetErrorString(e));
+    G.n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    e = hipMalloc((void**)&G.d_counters, 2 * sizeof(long long));
+    if (e == hipSuccess) e = hipMemset(G.d_counters, 0, 2 * sizeof(long long));
+    if (e == hipSuccess) e = hipStreamCreate(&G.insert_stream);
+    if (e != hipSuccess) return fail(VDB_ENOGPU, std::string("device set-up: ") + hipGetErrorString(e));
+    G.device = device;
+    G.inited = true;
+    return VDB_OK;
+}
+
+int vdb_shutdown(void) {
+    if (!G.inited) return VDB_OK;
+    (void)hipSetDevice(G.device);
+    (void)hipDeviceSynchronize();
+    std::vector<std::shared_ptr<Table>> ts;
+    {
+        std::lock_guard<std::mutex> lk(G.mu);
+        for (auto& kv : G.tables) ts.push_back(kv.second);
+        G.tables.clear();
+    }
+    for (auto& t : ts) {
+        std::unique_lock<std::shared_mutex> tl(t->mu);
+        table_free(*t);
+    }
+    std::lock_guard<std::mutex> lk(G.mu);
+    for (auto& w : G.free_ws) {
+        for (DevBuf* b : {&w->qprep, &w->qinfo, &w->cand_s, &w->cand_t, &w->need_exact, &w->q_raw,
+                          &w->o_ids, &w->o_scores, &w->o_counts})
+            if (b->p) (void)hipFree(b->p);
+        if (w->stream) (void)hipStreamDestroy(w->stream);
+        if (w->done) (void)hipEventDestroy(w->done);
+    }
+    G.free_ws.clear();
+    if (G.stage_rows.p) (void)hipFree(G.stage_rows.p);
+    if (G.stage_ids.p) (void)hipFree(G.stage_ids.p);
+    G.stage_rows = DevBuf(); G.stage_ids = DevBuf();
+    if (G.insert_stream) (void)hipStreamDestroy(G.insert_stream);
+    G.insert_stream = nullptr;
+    if (G.d_counters) (void)hipFree(G.d_counters);
+    G.d_counters = nullptr;
+    G.inited = false;
+    return VDB_OK;
+}
+
+int vdb_set_option(const char* key, double value) {
+    if (!key) return fail(VDB_EINVAL, "null option key");
+    std::lock_guard<std::mutex> lk(G.mu);
+    const std::string k(key);
+    if (k == "use_blas_threshold") { if (value < 1) return fail(VDB_EINVAL, "use_blas_threshold < 1"); G.use_blas_threshold = (int)value; }
+    else if (k == "cache_capacity_gb") { if (value < 0) return fail(VDB_EINVAL, "cache_capacity_gb < 0"); G.cache_capacity_gb = value; }
+    else if (k == "insert_buffer_size_gb") { if (value <= 0) return fail(VDB_EINVAL, "insert_buffer_size_gb <= 0"); G.insert_buffer_gb = value; }
+    else return fail(VDB_EINVAL, "unknown option: " + k);
+    return VDB_OK;
+}
+
+int vdb_create_table(const char* name, int64_t dim, int metric, int dtype) {
+    int rc = enter();
+    if (rc) return rc;
+    if (!name || !*name) return fail(VDB_EINVAL, "empty table name");
+    if (dim < 1 || dim > 16384) return fail(VDB_EINVAL, "dimension must be in [1, 16384]");
+    if (metric != VDB_METRIC_L2 && metric != VDB_METRIC_IP && metric != VDB_METRIC_COSINE)
+        return fail(VDB_EINVAL, "unknown metric");
+    if (dtype != VDB_F32 && dtype != VDB_BF16 && dtype != VDB_F16) return fail(VDB_EINVAL, "unknown dtype");
+    auto t = std::make_shared<Table>();
+    t->name = name; t->dim = dim; t->metric = metric; t->dtype = dtype;
+    const int epl = elems_per_unit(dtype);
+    t->m = (int)((dim + epl - 1) / epl);
+    t->dpad = t->m * epl;
+    VDB_HIP(hipMalloc((void**)&t->d_maxn2, sizeof(float)));
+    VDB_HIP(hipMemset(t->d_maxn2, 0, sizeof(float)));
+    std::lock_guard<std::mutex> lk(G.mu);
+    if (G.tables.count(name)) {
+        (void)hipFree(t->d_maxn2);
+        return fail(VDB_EEXISTS, std::string("table exists: ") + name);
+    }
+    G.tables[name] = t;
+    return VDB_OK;
+}
+
+int vdb_has_table(const char* name, int* out_exists) {
+    if (!G.inited) return fail(VDB_ESTATE, "vdb_init has not been called");
+    if (!name || !out_exists) return fail(VDB_EINVAL, "null argument");
+    *out_exists = find_table(name) ? 1 : 0;
+    return VDB_OK;
+}
+
+int vdb_drop_table(const char* name) {
+    int rc = enter();
+    if (rc) return rc;
+    if (!name) return fail(VDB_EINVAL, "null table name");
+    std::shared_ptr<Table> t;
+    {
+        std::lock_guard<std::mutex> lk(G.mu);
+        auto it = G.tables.find(name);
+        if (it == G.tables.end()) return fail(VDB_ENOTFOUND, std::string("no such table: ") + name);
+        t = it->second;
+        G.tables.erase(it);
+    }
+    std::unique_lock<std::shared_mutex> tl(t->mu);
+    table_free(*t);
+    return VDB_OK;
+}
+
+int vdb_create_index(const char* name, int index_type, int nlist) {
+    if (!G.inited) return fail(VDB_ESTATE, "vdb_init has not been called");
+    if (!name) return fail(VDB_EINVAL, "null table name");
+    if (!find_table(name)) return fail(VDB_ENOTFOUND, std::string("no such table: ") + name);
+    if (index_type != VDB_INDEX_FLAT && index_type != VDB_INDEX_IVFLAT) return fail(VDB_EINVAL, "unknown index type");
+    if (nlist < 0) return fail(VDB_EINVAL, "nlist < 0");
+    return VDB_OK;     // every search scans all rows: there is nothing to build
+}
+
+int vdb_count(const char* name, int64_t* out_rows) {
+    if (!G.inited) return fail(VDB_ESTATE, "vdb_init has not been called");
+    if (!name || !out_rows) return fail(VDB_EINVAL, "null argument");
+    auto t = find_table(name);
+    if (!t) return fail(VDB_ENOTFOUND, std::string("no such table: ") + name);
+    std::shared_lock<std::shared_mutex> tl(t->mu);
+    *out_rows = t->rows;
+    return VDB_OK;
+}
+
+int vdb_table_info(const char* name, int64_t* dim, int* metric, int* dtype, int64_t* rows,
+                   int64_t* capacity, int64_t* row_stride_bytes) {
+    if (!G.inited) return fail(VDB_ESTATE, "vdb_init has not been called");
+    if (!name) return fail(VDB_EINVAL, "null table name");
+    auto t = find_table(name);
+    if (!t) return fail(VDB_ENOTFOUND, std::string("no such table: ") + name);
+    std::shared_lock<std::shared_mutex> tl(t->mu);
+    if (dim) *dim = t->dim;
+    if (metric) *metric = t->metric;
+    if (dtype) *dtype = t->dtype;
+    if (rows) *rows = t->rows;
+    if (capacity) *capacity = t->cap;
+    if (row_stride_bytes) *row_stride_bytes = (int64_t)t->m * 16;
+    return VDB_OK;
+}
+
+int vdb_reserve(const char* name, int64_t rows) {
+    int rc = enter();
+    if (rc) return rc;
+    if (!name || rows < 0) return fail(VDB_EINVAL, "bad argument");
+    auto t = find_table(name);
+    if (!t) return fail(VDB_ENOTFOUND, std::string("no such table: ") + name);
+    std::unique_lock<std::shared_mutex> tl(t->mu);
+    if (t->dropped) return fail(VDB_ENOTFOUND, "table was dropped");
+    if (rows <= t->cap) return VDB_OK;
+    return table_alloc(*t, rows);
+}
+
+static int insert_common(const char* name, int64_t n, const float* rows, const long long* ids,
+                         bool host, bool synth, uint64_t seed, int64_t first_row, hipStream_t user_st) {
+    int rc = enter();
+    if (rc) return rc;
+    if (!name || n < 0) return fail(VDB_EINVAL, "bad argument");
+    if (!synth && n > 0 && (!rows || !ids)) return fail(VDB_EINVAL, "null rows or ids");
+    auto t = find_table(name);
+    if (!t) return fail(VDB_ENOTFOUND, std::string("no such table: ") + name);
+    if (n == 0) return VDB_OK;
+    std::unique_lock<std::shared_mutex> tl(t->mu);
+    if (t->dropped) return fail(VDB_ENOTFOUND, "table was dropped");
+    if ((rc = table_grow_for(*t, n))) return rc;
+    const int d = (int)t->dim;
+    if (synth) {
+        VDB_HIP(launch_append(t->d_rows, t->d_ids, t->d_n2, t->d_maxn2, t->rows, n, d, t->m, t->dtype,
+                              t->metric, nullptr, nullptr, seed, first_row, G.insert_stream));
+        VDB_HIP(hipStreamSynchronize(G.insert_stream));
+        t->rows += n;
+        return VDB_OK;
+    }
+    if (!host) {
+        hipStream_t st = user_st;
+        VDB_HIP(launch_append(t->d_rows, t->d_ids, t->d_n2, t->d_maxn2, t->rows, n, d, t->m, t->dtype,
+                              t->metric, rows, ids, 0, 0, st));
+        VDB_HIP(hipStreamSynchronize(st));   // rows become visible to searches on any stream
+        t->rows += n;
+        return VDB_OK;
+    }
+    std::lock_guard<std::mutex> il(G.insert_mu);
+    double cap_rows_d = G.insert_buffer_gb * 1073741824.0 / ((double)d * sizeof(float) + sizeof(long long));
+    int64_t chunk = cap_rows_d > 1e15 ? n : (int64_t)cap_rows_d;
+    if (chunk < 1) chunk = 1;
+    if (chunk > n) chunk = n;
+    if ((rc = ensure(G.stage_rows, (size_t)chunk * d * sizeof(float), G.insert_stream))) return rc;
+    if ((rc = ensure(G.stage_ids, (size_t)chunk * sizeof(long long), G.insert_stream))) return rc;
+    for (int64_t i0 = 0; i0 < n; i0 += chunk) {
+        const int64_t ni = n - i0 < chunk ? n - i0 : chunk;
+        VDB_HIP(hipMemcpyAsync(G.stage_rows.p, rows + (size_t)i0 * d, (size_t)ni * d * sizeof(float),
+                               hipMemcpyHostToDevice, G.insert_stream));
+        VDB_HIP(hipMemcpyAsync(G.stage_ids.p, ids + i0, (size_t)ni * sizeof(long long),
+                               hipMemcpyHostToDevice, G.insert_stream));
+        VDB_HIP(launch_append(t->d_rows, t->d_ids, t->d_n2, t->d_maxn2, t->rows, ni, d, t->m, t->dtype,
+                              t->metric, (const float*)G.stage_rows.p, (const long long*)G.stage_ids.p,
+                              0, 0, G.insert_stream));
+        VDB_HIP(hipStreamSynchronize(G.insert_stream));
+        t->rows += ni;
+    }
+    return VDB_OK;
+}
+
+int vdb_insert(const char* name, int64_t n, const float* rows, const int64_t* ids) {
+    return insert_common(name, n, rows, (const long long*)ids, true, false, 0, 0, nullptr);
+}
+
+int vdb_insert_dev(const char* name, int64_t n, const float* rows_dev, const int64_t* ids_dev, void* stream) {
+    return insert_common(name, n, rows_dev, (const long long*)ids_dev, false, false, 0, 0, (hipStream_t)stream);
+}
+
+int vdb_insert_synthetic(const char* name, int64_t n, uint64_t seed, int64_t first_row) {
+    return insert_common(name, n, nullptr, nullptr, false, true, seed, first_row, nullptr);
+}
+
+int vdb_synth_fill_dev(float* out_dev, int64_t n, int64_t dim, uint64_t seed, int64_t first_row, void* stream) {
+    int rc = enter();
+    if (rc) return rc;
+    if (!out_dev || n < 0 || dim < 1 || dim > 16384) return fail(VDB_EINVAL, "bad argument");
+    VDB_HIP(launch_synth_fill(out_dev, n, (int)dim, seed, first_row, (hipStream_t)stream));
+    return VDB_OK;
+}
+
+int vdb_fetch_rows(const char* name, int64_t first, int64_t n, float* out_rows, int64_t* out_ids) {
+    int rc = enter();
+    if (rc) return rc;
+    if (!name || first < 0 || n < 0) return fail(VDB_EINVAL, "bad argument");
+    auto t = find_table(name);
+    if (!t) return fail(VDB_ENOTFOUND, std::string("no such table: ") + name);
+    std::shared_lock<std::shared_mutex> tl(t->mu);
+    if (first + n > t->rows) return fail(VDB_EINVAL, "row range beyond the table");
+    if (n == 0) return VDB_OK;
+    if (out_rows) {
+        float* tmp = nullptr;
+        VDB_HIP(hipMalloc((void**)&tmp, (size_t)n * t->dim * sizeof(float)));
+        hipError_t e = launch_fetch_rows(t->d_rows, first, n, (int)t->dim, t->m, t->dtype, tmp, nullptr);
+        if (e == hipSuccess) e = hipMemcpy(out_rows, tmp, (size_t)n * t->dim * sizeof(float), hipMemcpyDeviceToHost);
+        (void)hipFree(tmp);
+        if (e != hipSuccess) return fail(VDB_EHIP, std::string("fetch rows: ") + hipGetErrorString(e));
+    }
+    if (out_ids) VDB_HIP(hipMemcpy(out_ids, t->d_ids + first, (size_t)n * sizeof(long long), hipMemcpyDeviceToHost));
+    return VDB_OK;
+}
+
+static int check_search_args(const char* name, int64_t nq, const void* q, int k, const void* a,
+                             const void* b, const void* c) {
+    if (!name || nq < 0) return fail(VDB_EINVAL, "bad argument");
+    if (k < 1 || k > VDB_MAX_TOPK) return fail(VDB_EINVAL, "k must be in [1, VDB_MAX_TOPK]");
+    if (nq > 0 && (!q || !a || !b || !c)) return fail(VDB_EINVAL, "null query or output pointer");
+    return VDB_OK;
+}
+
+int vdb_search_dev(const char* name, int64_t nq, const float* queries_dev, int k,
+                   int64_t* out_ids_dev, float* out_scores_dev, int32_t* out_counts_dev, void* stream) {
+    int rc = enter();
+    if (rc) return rc;
+    if ((rc = check_search_args(name, nq, queries_dev, k, out_ids_dev, out_scores_dev, out_counts_dev))) return rc;
+    auto t = find_table(name);
+    if (!t) return fail(VDB_ENOTFOUND, std::string("no such table: ") + name);
+    if (nq == 0) return VDB_OK;
+    hipStream_t st = (hipStream_t)stream;
+    std::unique_ptr<Workspace> ws;
+    if ((rc = acquire_ws(st, ws))) return rc;
+    {
+        std::shared_lock<std::shared_mutex> tl(t->mu);
+        if (t->dropped) rc = fail(VDB_ENOTFOUND, "table was dropped");
+        else rc = search_core(*t, nq, queries_dev, k, (long long*)out_ids_dev, out_scores_dev, out_counts_dev, st, *ws);
+    }
+    release_ws(ws, st);
+    return rc;
+}
+
+int vdb_search(const char* name, int64_t nq, const float* queries, int k,
+               int64_t* out_ids, float* out_scores, int32_t* out_counts) {
+    int rc = enter();
+    if (rc) return rc;
+    if ((rc = check_search_args(name, nq, queries, k, out_ids, out_scores, out_counts))) return rc;
+    auto t = find_table(name);
+    if (!t) return fail(VDB_ENOTFOUND, std::string("no such table: ") + name);
+    if (nq == 0) return VDB_OK;
+    std::unique_ptr<Workspace> ws;
+    if ((rc = acquire_ws(nullptr, ws))) return rc;
+    hipStream_t st = ws->stream;
+    const size_t d = (size_t)t->dim;
+    do {
+        if ((rc = ensure(ws->q_raw, (size_t)nq * d * sizeof(float), ws->last_stream))) break;
+        if ((rc = ensure(ws->o_ids, (size_t)nq * k * sizeof(long long), ws->last_stream))) break;
+        if ((rc = ensure(ws->o_scores, (size_t)nq * k * sizeof(float), ws->last_stream))) break;
+        if ((rc = ensure(ws->o_counts, (size_t)nq * sizeof(int), ws->last_stream))) break;
+        hipError_t e = hipMemcpyAsync(ws->q_raw.p, queries, (size_t)nq * d * sizeof(float), hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) { rc = fail(VDB_EHIP, std::string("query upload: ") + hipGetErrorString(e)); break; }
+        {
+            std::shared_lock<std::shared_mutex> tl(t->mu);
+            if (t->dropped) rc = fail(VDB_ENOTFOUND, "table was dropped");
+            else rc = search_core(*t, nq, (const float*)ws->q_raw.p, k, (long long*)ws->o_ids.p,
+                                  (float*)ws->o_scores.p, (int*)ws->o_counts.p, st, *ws);
+            if (rc == VDB_OK) {
+                e = hipMemcpyAsync(out_ids, ws->o_ids.p, (size_t)nq * k * sizeof(long long), hipMemcpyDeviceToHost, st);
+                if (e == hipSuccess) e = hipMemcpyAsync(out_scores, ws->o_scores.p, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, st);
+                if (e == hipSuccess) e = hipMemcpyAsync(out_counts, ws->o_counts.p, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, st);
+                if (e == hipSuccess) e = hipStreamSynchronize(st);
+                if (e != hipSuccess) rc = fail(VDB_EHIP, std::string("result download: ") + hipGetErrorString(e));
+            } else {
+                (void)hipStreamSynchronize(st);
+            }
+        }
+    } while (0);
+    release_ws(ws, st);
+    return rc;
+}
+
+int vdb_merge_topk_dev(int nparts, int64_t nq, int k, int metric, const int64_t* in_ids_dev,
+                       const float* in_scores_dev, const int32_t* in_counts_dev,
+                       int64_t* out_ids_dev, float* out_scores_dev, int32_t* out_counts_dev, void* stream) {
+    int rc = enter();
+    if (rc) return rc;
+    if (nparts < 1 || nq < 0 || k < 1 || k > VDB_MAX_TOPK) return fail(VDB_EINVAL, "bad argument");
+    if ((long long)nparts * k > 8192) return fail(VDB_EINVAL, "nparts * k exceeds 8192");
+    if (nq == 0) return VDB_OK;
+    if (!in_ids_dev || !in_scores_dev || !in_counts_dev || !out_ids_dev || !out_scores_dev || !out_counts_dev)
+        return fail(VDB_EINVAL, "null pointer");
+    VDB_HIP(launch_merge_topk(nparts, nq, k, metric,
+                              in_ids_dev, (size_t)nq * k * sizeof(long long),
+                              in_scores_dev, (size_t)nq * k * sizeof(float),
+                              in_counts_dev, (size_t)nq * sizeof(int),
+                              (long long*)out_ids_dev, out_scores_dev, out_counts_dev, (hipStream_t)stream));
+    return VDB_OK;
+}
+
+int64_t vdb_record_bytes(int64_t nq, int k) {
+    const int64_t b = nq * k * 12 + nq * 4;
+    return (b + 15) / 16 * 16;
+}
+
+int vdb_merge_records_dev(int nparts, int64_t nq, int k, int metric, const void* records_dev,
+                          int64_t* out_ids_dev, float* out_scores_dev, int32_t* out_counts_dev, void* stream) {
+    int rc = enter();
+    if (rc) return rc;
+    if (nparts < 1 || nq < 0 || k < 1 || k > VDB_MAX_TOPK) return fail(VDB_EINVAL, "bad argument");
+    if ((long long)nparts * k > 8192) return fail(VDB_EINVAL, "nparts * k exceeds 8192");
+    if (nq == 0) return VDB_OK;
+    if (!records_dev || !out_ids_dev || !out_scores_dev || !out_counts_dev) return fail(VDB_EINVAL, "null pointer");
+    const size_t stride = (size_t)vdb_record_bytes(nq, k);
+    const char* base = (const char*)records_dev;
+    VDB_HIP(launch_merge_topk(nparts, nq, k, metric, base, stride, base + (size_t)nq * k * 8, stride,
+                              base + (size_t)nq * k * 12, stride,
+                              (long long*)out_ids_dev, out_scores_dev, out_counts_dev, (hipStream_t)stream));
+    return VDB_OK;
+}
+
+int vdb_prof_enable(int on) {
+    G.prof_on.store(on ? 1 : 0);
+    return VDB_OK;
+}
+
+int vdb_prof_read(double* scan_ms, int64_t* scan_launches) {
+    int rc = enter();
+    if (rc) return rc;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
+    {
+        std::lock_guard<std::mutex> lk(G.prof_mu);
+        evs.swap(G.prof_events);
+    }
+    double ms = 0.0;
+    for (auto& ev : evs) {
+        VDB_HIP(hipEventSynchronize(ev.second));
+        float t = 0.f;
+        VDB_HIP(hipEventElapsedTime(&t, ev.first, ev.second));
+        ms += t;
+    }
+    if (scan_ms) *scan_ms = ms;
+    if (scan_launches) *scan_launches = (int64_t)evs.size();
+    std::lock_guard<std::mutex> lk(G.prof_mu);
+    for (auto& ev : evs) G.prof_pool.push_back(ev);
+    return VDB_OK;
+}
+
+int vdb_stats(int64_t* queries, int64_t* exact_fallbacks) {
+    int rc = enter();
+    if (rc) return rc;
+    long long h[2] = {0, 0};
+    VDB_HIP(hipDeviceSynchronize());
+    VDB_HIP(hipMemcpy(h, G.d_counters, sizeof(h), hipMemcpyDeviceToHost));
+    if (queries) *queries = h[0];
+    if (exact_fallbacks) *exact_fallbacks = h[1];
+    return VDB_OK;
+}
+
+}  // extern "C"

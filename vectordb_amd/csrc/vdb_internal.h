@@ -1,0 +1,91 @@
+// Internal declarations shared by the kernel translation units and the C-ABI layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/vdb.h"
+
+namespace vdb {
+
+// One prepared query: what the certificate of the fast pass needs besides the vector itself.
+struct QInfo {
+    double n2;     // canonical fp64 squared norm of the prepared query
+    float  bq;     // upper bound of its Euclidean norm
+    float  pad;
+};
+
+// Geometry of a stored table as the kernels see it.
+struct TableView {
+    const char*      rows;      // [n][m*16 bytes], row-major, zero padded to a 16-byte multiple
+    const long long* ids;       // [n]
+    const float*     n2;        // [n] fp32 squared norm of the stored row
+    const float*     max_n2;    // device scalar: max over rows of n2
+    long long        n;
+    int              d;         // logical dimension
+    int              m;         // 16-byte units per row
+    int              dt;        // VDB_F32 / VDB_BF16 / VDB_F16
+    int              metric;    // VDB_METRIC_*
+};
+
+inline int elems_per_unit(int dt) { return dt == VDB_F32 ? 4 : 8; }
+
+// Candidate-list sizing for a given k (host side).
+struct SelGeom {
+    int K;   // candidates kept per list (k plus a safety margin for the fp32 scoring error)
+    int C;   // list capacity in LDS (power of two, >= 2K and >= K+64)
+    int W;   // waves per scan block
+};
+SelGeom sel_geom(int k);
+
+// Scratch memory of one search call (device pointers).
+struct SearchScratch {
+    float*     qprep;       // [nq][dpad]
+    QInfo*     qinfo;       // [nq]
+    float*     cand_s;      // [nq][G][K]
+    long long* cand_t;      // [nq][G][K]
+    int*       need_exact;  // [nq]
+    long long* counters;    // [2]: queries, exact fallbacks (library-wide, not per scratch)
+};
+
+// ---- launchers (all asynchronous on `st`) -------------------------------------------------
+hipError_t launch_prep_query(const float* q_raw, int64_t nq, int d, int dpad, int metric,
+                             float* qprep, QInfo* qinfo, hipStream_t st);
+
+// Fast pass: fp32 scoring of every row, top-K candidates per (query, block).
+// Returns the grid width G through *out_G (cand arrays must hold nq*G*K entries; use scan_grid()).
+int  scan_grid(const TableView& t, const SelGeom& g, int n_cu);
+hipError_t launch_scan(const TableView& t, const float* qprep, int64_t nq, int dpad,
+                       const SelGeom& g, int G, float* cand_s, long long* cand_t, hipStream_t st);
+
+// Merge candidates, re-score them canonically (fp64), order by (score, id), certify.
+hipError_t launch_finalize(const TableView& t, const float* qprep, const QInfo* qinfo, int64_t nq,
+                           int dpad, const SelGeom& g, int G, int k,
+                           const float* cand_s, const long long* cand_t,
+                           long long* out_ids, float* out_scores, int* out_counts,
+                           int* need_exact, long long* counters, hipStream_t st);
+
+// Exact second pass for the queries whose fast pass could not be certified.
+hipError_t launch_exact(const TableView& t, const float* qprep, int64_t nq, int dpad,
+                        const SelGeom& g, int G, int k, float* cand_s, long long* cand_t,
+                        long long* out_ids, float* out_scores, int* out_counts,
+                        int* need_exact, long long* counters, hipStream_t st);
+
+// Append n rows (raw fp32 from `raw`, or synthetic when raw == nullptr) at row index `row0`.
+hipError_t launch_append(char* rows, long long* ids, float* n2, float* max_n2,
+                         long long row0, long long n, int d, int m, int dt, int metric,
+                         const float* raw, const long long* raw_ids,
+                         uint64_t seed, long long synth_first_row, hipStream_t st);
+
+hipError_t launch_synth_fill(float* out, long long n, int d, uint64_t seed, long long first_row,
+                             hipStream_t st);
+
+hipError_t launch_fetch_rows(const char* rows, long long first, long long n, int d, int m, int dt,
+                             float* out, hipStream_t st);
+
+hipError_t launch_merge_topk(int nparts, int64_t nq, int k, int metric,
+                             const void* in_ids, size_t ids_stride,
+                             const void* in_scores, size_t scores_stride,
+                             const void* in_counts, size_t counts_stride,
+                             long long* out_ids, float* out_scores, int* out_counts,
+                             hipStream_t st);
+
+}  // namespace vdb

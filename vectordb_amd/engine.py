@@ -1,0 +1,156 @@
+"""Host-side wrapper over the C ABI: numpy in, numpy out, plus device-pointer entry points for
+callers that keep queries and results in HBM (PyTorch tensors supply the pointers).
+
+All arithmetic happens in libvdb.so on the GPU; this module only marshals arguments.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import threading
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import (F16, F32, BF16, METRIC_COSINE, METRIC_IP, METRIC_L2, VdbError, check)
+from .config import EngineConfig
+
+_init_lock = threading.Lock()
+
+
+def _name(s: str) -> bytes:
+    return s.encode("utf-8")
+
+
+class Engine:
+    """One process-wide engine bound to one GPU."""
+
+    def __init__(self, device: int = 0, config: Optional[EngineConfig] = None):
+        self.lib = _lib.load()
+        with _init_lock:
+            check(self.lib.vdb_init(int(device)))
+        self.device = int(device)
+        self.config = config or EngineConfig()
+        check(self.lib.vdb_set_option(b"use_blas_threshold", float(self.config.use_blas_threshold)))
+        check(self.lib.vdb_set_option(b"cache_capacity_gb", float(self.config.cache_capacity_gb)))
+        check(self.lib.vdb_set_option(b"insert_buffer_size_gb", float(self.config.insert_buffer_size_gb)))
+
+    # ---- lifecycle
+    def create_table(self, name: str, dim: int, metric: int = METRIC_IP, dtype: int = F32) -> None:
+        check(self.lib.vdb_create_table(_name(name), int(dim), int(metric), int(dtype)))
+
+    def has_table(self, name: str) -> bool:
+        out = C.c_int(0)
+        check(self.lib.vdb_has_table(_name(name), C.byref(out)))
+        return bool(out.value)
+
+    def drop_table(self, name: str) -> None:
+        check(self.lib.vdb_drop_table(_name(name)))
+
+    def create_index(self, name: str, index_type: int = _lib.INDEX_IVFLAT, nlist: int = 2048) -> None:
+        check(self.lib.vdb_create_index(_name(name), int(index_type), int(nlist)))
+
+    def count(self, name: str) -> int:
+        out = C.c_int64(0)
+        check(self.lib.vdb_count(_name(name), C.byref(out)))
+        return int(out.value)
+
+    def reserve(self, name: str, rows: int) -> None:
+        check(self.lib.vdb_reserve(_name(name), int(rows)))
+
+    def table_info(self, name: str) -> dict:
+        dim, rows, cap, stride = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        metric, dtype = C.c_int(), C.c_int()
+        check(self.lib.vdb_table_info(_name(name), C.byref(dim), C.byref(metric), C.byref(dtype),
+                                      C.byref(rows), C.byref(cap), C.byref(stride)))
+        return dict(dim=dim.value, metric=metric.value, dtype=dtype.value, rows=rows.value,
+                    capacity=cap.value, row_stride_bytes=stride.value)
+
+    # ---- append
+    def insert(self, name: str, rows, ids) -> None:
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        if rows.ndim == 1:
+            rows = rows[None, :]
+        ids = np.ascontiguousarray(ids, dtype=np.int64).reshape(-1)
+        if rows.shape[0] != ids.shape[0]:
+            raise VdbError(_lib.EINVAL, "rows and ids differ in length")
+        info = self.table_info(name)
+        if rows.shape[0] and rows.shape[1] != info["dim"]:
+            raise VdbError(_lib.EINVAL, "row dimension %d does not match the table's %d" % (rows.shape[1], info["dim"]))
+        check(self.lib.vdb_insert(_name(name), rows.shape[0], rows.ctypes.data, ids.ctypes.data))
+
+    def insert_dev(self, name: str, n: int, rows_ptr: int, ids_ptr: int, stream: int = 0) -> None:
+        check(self.lib.vdb_insert_dev(_name(name), int(n), C.c_void_p(rows_ptr), C.c_void_p(ids_ptr),
+                                      C.c_void_p(stream)))
+
+    def insert_synthetic(self, name: str, n: int, seed: int, first_row: int = 0) -> None:
+        check(self.lib.vdb_insert_synthetic(_name(name), int(n), int(seed), int(first_row)))
+
+    def synth_fill_dev(self, out_ptr: int, n: int, dim: int, seed: int, first_row: int = 0, stream: int = 0) -> None:
+        check(self.lib.vdb_synth_fill_dev(C.c_void_p(out_ptr), int(n), int(dim), int(seed), int(first_row),
+                                          C.c_void_p(stream)))
+
+    def fetch_rows(self, name: str, first: int, n: int) -> Tuple[np.ndarray, np.ndarray]:
+        info = self.table_info(name)
+        rows = np.empty((n, info["dim"]), dtype=np.float32)
+        ids = np.empty((n,), dtype=np.int64)
+        check(self.lib.vdb_fetch_rows(_name(name), int(first), int(n), rows.ctypes.data, ids.ctypes.data))
+        return rows, ids
+
+    # ---- search
+    def search(self, name: str, queries, k: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """queries [nq, d] -> (ids [nq,k] int64, scores [nq,k] fp32, counts [nq] int32)."""
+        queries = np.ascontiguousarray(queries, dtype=np.float32)
+        if queries.ndim == 1:
+            queries = queries[None, :]
+        nq = queries.shape[0]
+        info = self.table_info(name)
+        if nq and queries.shape[1] != info["dim"]:
+            raise VdbError(_lib.EINVAL, "query dimension %d does not match the table's %d" % (queries.shape[1], info["dim"]))
+        ids = np.full((nq, k), -1, dtype=np.int64)
+        scores = np.zeros((nq, k), dtype=np.float32)
+        counts = np.zeros((nq,), dtype=np.int32)
+        check(self.lib.vdb_search(_name(name), nq, queries.ctypes.data, int(k),
+                                  ids.ctypes.data, scores.ctypes.data, counts.ctypes.data))
+        return ids, scores, counts
+
+    def search_dev(self, name: str, nq: int, queries_ptr: int, k: int, out_ids_ptr: int,
+                   out_scores_ptr: int, out_counts_ptr: int, stream: int = 0) -> None:
+        check(self.lib.vdb_search_dev(_name(name), int(nq), C.c_void_p(queries_ptr), int(k),
+                                      C.c_void_p(out_ids_ptr), C.c_void_p(out_scores_ptr),
+                                      C.c_void_p(out_counts_ptr), C.c_void_p(stream)))
+
+    def merge_topk_dev(self, nparts: int, nq: int, k: int, metric: int, in_ids_ptr: int, in_scores_ptr: int,
+                       in_counts_ptr: int, out_ids_ptr: int, out_scores_ptr: int, out_counts_ptr: int,
+                       stream: int = 0) -> None:
+        check(self.lib.vdb_merge_topk_dev(int(nparts), int(nq), int(k), int(metric),
+                                          C.c_void_p(in_ids_ptr), C.c_void_p(in_scores_ptr),
+                                          C.c_void_p(in_counts_ptr), C.c_void_p(out_ids_ptr),
+                                          C.c_void_p(out_scores_ptr), C.c_void_p(out_counts_ptr),
+                                          C.c_void_p(stream)))
+
+    def record_bytes(self, nq: int, k: int) -> int:
+        return int(self.lib.vdb_record_bytes(int(nq), int(k)))
+
+    def merge_records_dev(self, nparts: int, nq: int, k: int, metric: int, records_ptr: int,
+                          out_ids_ptr: int, out_scores_ptr: int, out_counts_ptr: int, stream: int = 0) -> None:
+        check(self.lib.vdb_merge_records_dev(int(nparts), int(nq), int(k), int(metric), C.c_void_p(records_ptr),
+                                             C.c_void_p(out_ids_ptr), C.c_void_p(out_scores_ptr),
+                                             C.c_void_p(out_counts_ptr), C.c_void_p(stream)))
+
+    # ---- measurement
+    def prof_enable(self, on: bool) -> None:
+        check(self.lib.vdb_prof_enable(1 if on else 0))
+
+    def prof_read(self) -> Tuple[float, int]:
+        ms, n = C.c_double(0.0), C.c_int64(0)
+        check(self.lib.vdb_prof_read(C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)
+
+    def stats(self) -> Tuple[int, int]:
+        q, f = C.c_int64(0), C.c_int64(0)
+        check(self.lib.vdb_stats(C.byref(q), C.byref(f)))
+        return int(q.value), int(f.value)
+
+    def shutdown(self) -> None:
+        check(self.lib.vdb_shutdown())
