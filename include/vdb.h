@@ -66,7 +66,9 @@ int vdb_shutdown(void);
 /* Knobs of /root/reference/server_config.yaml, forwarded by the host shim after it has read
  * that file: "use_blas_threshold" (:36, batch size from which the MFMA GEMM path is used),
  * "cache_capacity_gb" (:42, HBM budget for all tables, 0 = unlimited),
- * "insert_buffer_size_gb" (:19, pinned host staging for host inserts). */
+ * "insert_buffer_size_gb" (:19, pinned host staging for host inserts).
+ * Launch tunables of the scan kernel (defaults are the measured best): "scan_nt",
+ * "scan_waves", "scan_blocks_per_cu", "scan_contiguous". */
 int vdb_set_option(const char* key, double value);
 const char* vdb_last_error(void);
 
@@ -140,6 +142,9 @@ int vdb_prof_enable(int on);
 /* Synchronises the recorded events; returns summed scan-kernel milliseconds and launch count
  * since the last call, and resets both. */
 int vdb_prof_read(double* scan_ms, int64_t* scan_launches);
+/* Reads `bytes` of a device buffer with the scan's access shape and no scoring: the read-bandwidth
+ * ceiling the scan's achieved GB/s is compared with (tools/tune_scan.py). */
+int vdb_bench_read_dev(const void* buf_dev, int64_t bytes, int nt, int blocks, int threads, void* stream);
 /* counters since init: searches (queries), queries that needed the exact second pass */
 int vdb_stats(int64_t* queries, int64_t* exact_fallbacks);
 

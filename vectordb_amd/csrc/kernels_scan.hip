@@ -35,8 +35,17 @@ __device__ __forceinline__ float load_elem(const char* row, int j, int dt) {
     return f16_bits(b);
 }
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// 16-byte row load; NT = non-temporal cache policy (rows are read once per scan)
+template <bool NT>
+__device__ __forceinline__ u32x4 load16(const char* p) {
+    if constexpr (NT) return __builtin_nontemporal_load((const u32x4*)p);
+    else return *(const u32x4*)p;
+}
+
 template <int DT>
-__device__ __forceinline__ float dot_unit(const uint4& x, const float* q, float acc) {
+__device__ __forceinline__ float dot_unit(const u32x4& x, const float* q, float acc) {
     if constexpr (DT == VDB_F32) {
         acc = fmaf(__uint_as_float(x.x), q[0], acc);
         acc = fmaf(__uint_as_float(x.y), q[1], acc);
@@ -63,19 +72,31 @@ __device__ __forceinline__ double wave_tree_sum(double acc) {
 }
 
 // Canonical fp64 score of one stored row against a prepared query, computed by one wave.
-// Every lane returns the same value.
+// Every lane returns the same value.  Lane l owns elements l, l+64, ... in increasing order;
+// sixteen of them are fetched per round trip.  Elements past d are taken as zero, which leaves
+// the sum unchanged bit for bit (the accumulator is never -0.0).
 __device__ __forceinline__ double canon_score(const char* row, const float* q, int d, int dt,
                                               bool l2, int lane) {
 #pragma clang fp contract(off)
     double acc = 0.0;
-    for (int j = lane; j < d; j += 64) {
-        const double x = (double)load_elem(row, j, dt);
-        const double y = (double)q[j];
-        if (l2) {
-            const double df = __dsub_rn(x, y);
-            acc = __dadd_rn(acc, __dmul_rn(df, df));
-        } else {
-            acc = __dadd_rn(acc, __dmul_rn(x, y));   // product exact: same as an fma
+    for (int j0 = lane; j0 < d; j0 += 64 * 16) {
+        float xv[16], yv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int j = j0 + 64 * u;
+            const bool ok = j < d;
+            xv[u] = ok ? load_elem(row, j, dt) : 0.f;
+            yv[u] = ok ? q[j] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const double x = (double)xv[u], y = (double)yv[u];
+            if (l2) {
+                const double df = __dsub_rn(x, y);
+                acc = __dadd_rn(acc, __dmul_rn(df, df));
+            } else {
+                acc = __dadd_rn(acc, __dmul_rn(x, y));   // product exact: same as an fma
+            }
         }
     }
     return wave_tree_sum(acc);
@@ -138,9 +159,22 @@ struct ScanParams {
     int          dpad;
     int          K, C;
     int          l2;
+    int          contiguous;
     float*       cand_s;    // [nq][G][K]
     long long*   cand_t;
 };
+
+// Launch tunables of the scan (set through vdb_set_option, defaults chosen by measurement).
+struct ScanTune {
+    int nt = 1;              // non-temporal row loads (+13 % over the default cache policy)
+    int waves = 8;           // waves per block (upper bound; the candidate-list geometry may lower it)
+    int blocks_per_cu = 4;   // grid cap in blocks per CU (two are resident, two queue behind them)
+    int contiguous = 1;      // 1 = each wave scans one contiguous range instead of interleaving
+};
+static ScanTune g_tune;
+void set_scan_tune(int nt, int waves, int blocks_per_cu, int contiguous) {
+    g_tune.nt = nt; g_tune.waves = waves; g_tune.blocks_per_cu = blocks_per_cu; g_tune.contiguous = contiguous;
+}
 
 template <int NCH> struct ScanUnroll { static constexpr int U = (NCH <= 1) ? 8 : (NCH <= 3) ? 4 : (NCH <= 6) ? 2 : 1; };
 
@@ -148,7 +182,7 @@ template <int NCH> struct ScanUnroll { static constexpr int U = (NCH <= 1) ? 8 :
 // such instructions (NCH > 1 only with LPR == 64).  Every load is unconditional: lanes past the
 // end of a row re-read its first 16 bytes against a zero query, rows past the end of the table
 // re-read the last row and are discarded.
-template <int DT, int LPR, int NCH>
+template <int DT, int LPR, int NCH, bool NT>
 __global__ void __launch_bounds__(1024)
 scan_kernel(ScanParams p) {
     constexpr int EPL = (DT == VDB_F32) ? 4 : 8;
@@ -187,8 +221,8 @@ scan_kernel(ScanParams p) {
     const long long last = p.n - 1;
 
     for (long long st = 0; st < nsteps; ++st) {
-        const long long base = (st * TW + gw) * RPS;
-        uint4 x[U][NCH];
+        const long long base = p.contiguous ? (gw * nsteps + st) * RPS : (st * TW + gw) * RPS;
+        u32x4 x[U][NCH];
         float nn[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -196,7 +230,7 @@ scan_kernel(ScanParams p) {
             const long long rc = r < last ? r : last;
             const char* ptr = p.rows + (size_t)rc * rowbytes;
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) x[u][c] = *(const uint4*)(ptr + off[c]);
+            for (int c = 0; c < NCH; ++c) x[u][c] = load16<NT>(ptr + off[c]);
             nn[u] = p.l2 ? p.n2[rc] : 0.f;
         }
 #pragma unroll
@@ -266,9 +300,9 @@ scan_kernel_generic(ScanParams p) {
             float qv[EPL];
 #pragma unroll
             for (int e = 0; e < EPL; ++e) qv[e] = qs[unit * EPL + e];
-            uint4 x[U];
+            u32x4 x[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) x[u] = *(const uint4*)(ptr[u] + o);
+            for (int u = 0; u < U; ++u) x[u] = load16<true>(ptr[u] + o);
 #pragma unroll
             for (int u = 0; u < U; ++u) acc[u] = dot_unit<DT>(x[u], qv, acc[u]);
         }
@@ -321,7 +355,8 @@ int scan_grid(const TableView& t, const SelGeom& g, int n_cu) {
     long long need = (t.n + per - 1) / per;
     if (need < 1) need = 1;
     // LDS and the 1024-thread bound admit one 16-wave block per CU; smaller blocks pack more.
-    const long long cap = (long long)n_cu * (g.W >= 16 ? 1 : (16 / g.W));
+    long long cap = (long long)n_cu * (g.W >= 16 ? 1 : (16 / g.W));
+    if (g_tune.blocks_per_cu > 0) cap = (long long)n_cu * g_tune.blocks_per_cu;
     return (int)(need < cap ? need : cap);
 }
 
@@ -330,7 +365,8 @@ static hipError_t launch_scan_dt(const ScanShape& s, dim3 grid, dim3 block, size
                                  const ScanParams& p, hipStream_t st) {
 #define VDB_SCAN_CASE(L, N)                                                                       \
     if (s.lpr == L && s.nch == N) {                                                               \
-        hipLaunchKernelGGL((scan_kernel<DT, L, N>), grid, block, lds, st, p);                     \
+        if (g_tune.nt) hipLaunchKernelGGL((scan_kernel<DT, L, N, true>), grid, block, lds, st, p);  \
+        else hipLaunchKernelGGL((scan_kernel<DT, L, N, false>), grid, block, lds, st, p);          \
         return hipGetLastError();                                                                 \
     }
     if (!s.generic) {
@@ -353,6 +389,7 @@ hipError_t launch_scan(const TableView& t, const float* qprep, int64_t nq, int d
     ScanParams p;
     p.rows = t.rows; p.n2 = t.n2; p.q = qprep; p.n = t.n; p.m = t.m; p.dpad = dpad;
     p.K = g.K; p.C = g.C; p.l2 = (t.metric == VDB_METRIC_L2) ? 1 : 0;
+    p.contiguous = g_tune.contiguous;
     p.cand_s = cand_s; p.cand_t = cand_t;
     const ScanShape s = scan_shape(t.m, t.dt);
     const dim3 grid((unsigned)G, (unsigned)nq), block((unsigned)g.W * 64);
@@ -362,6 +399,36 @@ hipError_t launch_scan(const TableView& t, const float* qprep, int64_t nq, int d
         case VDB_BF16: return launch_scan_dt<VDB_BF16>(s, grid, block, lds, p, st);
         default:       return launch_scan_dt<VDB_F16>(s, grid, block, lds, p, st);
     }
+}
+
+// ------------------------------------------------------------------------------ read ceiling
+// Streams a buffer with the scan's access shape (16 bytes per lane, 12 loads in flight per wave)
+// and almost no arithmetic: the read bandwidth this chip grants such a kernel, measured beside
+// the scan by the tuning script.
+template <bool NT>
+__global__ void __launch_bounds__(1024)
+read_bw_kernel(const char* __restrict__ buf, long long units, unsigned int* __restrict__ sink) {
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nthreads = (long long)gridDim.x * blockDim.x;
+    unsigned int acc = 0;
+    long long i = tid;
+    for (; i + 11 * nthreads < units; i += 12 * nthreads) {
+        u32x4 x[12];
+#pragma unroll
+        for (int j = 0; j < 12; ++j) x[j] = load16<NT>(buf + (size_t)(i + j * nthreads) * 16);
+#pragma unroll
+        for (int j = 0; j < 12; ++j) acc ^= x[j].x ^ x[j].y ^ x[j].z ^ x[j].w;
+    }
+    for (; i < units; i += nthreads) { const u32x4 x = load16<NT>(buf + (size_t)i * 16); acc ^= x.x ^ x.y ^ x.z ^ x.w; }
+    if (acc == 0x9e3779b9u) sink[0] = acc;     // keeps the loads alive, practically never taken
+}
+
+hipError_t launch_read_bw(const void* buf, long long bytes, int nt, int blocks, int threads,
+                          unsigned int* sink, hipStream_t st) {
+    const long long units = bytes / 16;
+    if (nt) hipLaunchKernelGGL((read_bw_kernel<true>), dim3((unsigned)blocks), dim3((unsigned)threads), 0, st, (const char*)buf, units, sink);
+    else hipLaunchKernelGGL((read_bw_kernel<false>), dim3((unsigned)blocks), dim3((unsigned)threads), 0, st, (const char*)buf, units, sink);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------ finalize
@@ -382,30 +449,186 @@ struct FinParams {
 
 __device__ __forceinline__ int pow2_ceil_dev(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
+// Order-preserving map of an fp32 score onto uint32 (larger score -> larger key).
+__device__ __forceinline__ uint32_t fkey(float s) {
+    const uint32_t u = __float_as_uint(s);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(uint32_t k) {
+    return (k & 0x80000000u) ? __uint_as_float(k & 0x7fffffffu) : __uint_as_float(~k);
+}
+
+// One histogram increment per distinct bin per wave instead of one per lane: scores of the
+// candidates share their leading bits, so a plain per-lane LDS atomic would serialise 64-fold.
+__device__ __forceinline__ void hist_add_aggregated(int* hist, bool active, int bin) {
+    unsigned long long todo = __ballot(active);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int b = __shfl(bin, leader);
+        const unsigned long long same = __ballot(active && bin == b) & todo;
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[b], __popcll(same));
+        todo &= ~same;
+    }
+}
+
+// Block-wide K-th largest of `count` fp32 values by an 8-bit MSD radix select (four histogram
+// passes, no sorting).  `get(i, u)` returns value i (-inf = empty, never counted); u is the slot
+// of the 8-wide batch, a compile-time constant after unrolling, so that a source of at most
+// 8 * blockDim.x values may sit in registers (slot u <-> value u * blockDim.x + tid).  On return:
+// ctl[4] = number of real values; if that is <= K the caller takes them all (returns true);
+// otherwise `thr` is the key of the K-th largest and `need` how many values equal to it belong
+// to the K (all values with a larger key do).  Called by every thread of the block.
+template <typename F>
+__device__ __forceinline__ bool select_kth(F get, long long count, int K, int* hist, int* ctl,
+                                           uint32_t& thr, int& need) {
+    const int nth = blockDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t prefix = 0;
+    need = K;
+    for (int pass = 0; pass < 4; ++pass) {
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        const int shift = 24 - 8 * pass;
+        for (long long i0 = 0; i0 < count; i0 += (long long)nth * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const long long i = i0 + (long long)u * nth + tid; v[u] = (i < count) ? get(i, u) : neg_inf(); }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (i0 + (long long)u * nth < count) {             // block-uniform
+                    const uint32_t key = fkey(v[u]);
+                    const bool act = (v[u] > neg_inf()) && (pass == 0 || (key >> (shift + 8)) == prefix);
+                    hist_add_aggregated(hist, act, (int)((key >> shift) & 255u));
+                }
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            int h[4], tot = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { h[j] = hist[255 - 4 * lane - j]; tot += h[j]; }
+            int incl = tot;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+            const int excl = incl - tot;
+            if (pass == 0 && lane == 63) ctl[4] = incl;
+            if (excl < need && need <= incl) {
+                int acc = excl;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (acc < need && need <= acc + h[j]) { ctl[0] = (int)((prefix << 8) | (uint32_t)(255 - 4 * lane - j)); ctl[1] = need - acc; }
+                    acc += h[j];
+                }
+            }
+        }
+        __syncthreads();
+        if (pass == 0 && ctl[4] <= K) return true;
+        prefix = (uint32_t)ctl[0];
+        need = ctl[1];
+    }
+    thr = prefix;
+    return false;
+}
+
+constexpr int FIN_CAP = 2048;     // survivors of the pre-filter kept in LDS
+
+// One block per query.  The G per-block candidate lists arrive sorted, so the K-th largest list
+// head is a lower bound of the K-th best key overall; everything below it is dropped with one
+// compare per candidate, and the exact K best are radix-selected among the few survivors.  The
+// K rows are then re-scored canonically, sorted by (score, id) and the answer is certified.
 __global__ void __launch_bounds__(1024)
 finalize_kernel(FinParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int W = blockDim.x >> 6;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float*     S_all = (float*)smem;
-    long long* T_all = (long long*)(smem + (size_t)W * p.C * sizeof(float));
-    const int KR = pow2_ceil_dev(p.K);
-    long long* RT = (long long*)(smem + (size_t)W * p.C * (sizeof(float) + sizeof(long long)));
-    float*     RS = (float*)(RT + KR);
-    int*       s_nvalid = (int*)(RS + KR);      // all LDS lives in the one dynamic region
+    const int nth = blockDim.x;
+    const int W = nth >> 6;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int K = p.K;
+    const int KR = pow2_ceil_dev(K);
+    int*       hist = (int*)smem;                       // 256 bins
+    int*       ctl  = hist + 256;                       // 16 control words
+    long long* ST   = (long long*)(smem + 1088);        // K selected tags (row indices)
+    float*     SS   = (float*)(ST + K);                 // K selected fast keys
+    long long* RT   = (long long*)(SS + K);             // KR re-scored ids
+    float*     RS   = (float*)(RT + KR);                // KR re-scored keys
+    float*     VS   = RS + KR;                          // FIN_CAP survivor keys
+    int*       VI   = (int*)(VS + FIN_CAP);             // FIN_CAP survivor positions
 
     const int qi = blockIdx.x;
-    const long long ncand = (long long)p.G * p.K;
-    block_topk_global(p.cand_s + (size_t)qi * ncand, p.cand_t + (size_t)qi * ncand, ncand,
-                      S_all, T_all, p.C, p.K, W, wave, lane);
-    // S_all/T_all[0..K): best fast keys with row indices (TAG_NONE = empty), sorted.
-    if (threadIdx.x == 0) {
-        int nv = 0;
-        while (nv < p.K && T_all[nv] != TAG_NONE) ++nv;
-        *s_nvalid = nv;
+    const long long M = (long long)p.G * K;
+    const float*     gs = p.cand_s + (size_t)qi * M;
+    const long long* gt = p.cand_t + (size_t)qi * M;
+
+    if (tid < 16) ctl[tid] = 0;
+    __syncthreads();
+    uint32_t thr = 0;
+    int need = K;
+    bool take_all;
+
+    // (A) lower bound from the list heads
+    uint32_t lb = 0;
+    if (p.G > K) {
+        int nd;
+        bool all;
+        if (p.G <= 8 * nth) {
+            float head[8];                       // read once, reused by the four passes
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const long long b = (long long)u * nth + tid; head[u] = (b < p.G) ? gs[b * K] : neg_inf(); }
+            all = select_kth([&](long long, int u) { return head[u]; }, (long long)p.G, K, hist, ctl, lb, nd);
+        } else {
+            all = select_kth([&](long long b, int) { return gs[b * K]; }, (long long)p.G, K, hist, ctl, lb, nd);
+        }
+        if (all) lb = 0;
+        __syncthreads();
+    }
+    // (B) survivors of the lower bound, appended wave by wave
+    for (long long i0 = 0; i0 < M; i0 += (long long)nth * 32) {
+        float v[32];                             // 32 loads in flight: one round trip per 32*nth candidates
+#pragma unroll
+        for (int u = 0; u < 32; ++u) { const long long i = i0 + (long long)u * nth + tid; v[u] = (i < M) ? gs[i] : neg_inf(); }
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            if (i0 + (long long)u * nth >= M) continue;              // block-uniform
+            const bool pass = (v[u] > neg_inf()) && fkey(v[u]) >= lb;
+            const unsigned long long m = __ballot(pass);
+            if (m) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&ctl[5], __popcll(m));
+                base = __shfl(base, 0);
+                const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+                if (pass && pos < FIN_CAP) { VS[pos] = v[u]; VI[pos] = (int)(i0 + (long long)u * nth + tid); }
+            }
+        }
     }
     __syncthreads();
-    const int nvalid = *s_nvalid;
+    const int S = ctl[5];
+    if (S <= FIN_CAP) {
+        // (C) exact K best among the survivors
+        take_all = select_kth([&](long long j, int) { return VS[j]; }, (long long)S, K, hist, ctl, thr, need);
+        for (int j = tid; j < S; j += nth) {
+            const float sc = VS[j];
+            const uint32_t key = fkey(sc);
+            int pos = -1;
+            if (take_all || key > thr) pos = atomicAdd(&ctl[2], 1);
+            else if (key == thr) { const int e = atomicAdd(&ctl[3], 1); if (e < need) pos = (K - need) + e; }
+            if (pos >= 0 && pos < K) { SS[pos] = sc; ST[pos] = gt[VI[j]]; }
+        }
+    } else {
+        // more survivors than the buffer holds (massive ties): select over all candidates
+        take_all = select_kth([&](long long i, int) { return gs[i]; }, M, K, hist, ctl, thr, need);
+        for (long long i = tid; i < M; i += nth) {
+            const float sc = gs[i];
+            if (!(sc > neg_inf())) continue;
+            const uint32_t key = fkey(sc);
+            int pos = -1;
+            if (take_all || key > thr) pos = atomicAdd(&ctl[2], 1);
+            else if (key == thr) { const int e = atomicAdd(&ctl[3], 1); if (e < need) pos = (K - need) + e; }
+            if (pos >= 0 && pos < K) { SS[pos] = sc; ST[pos] = gt[i]; }
+        }
+    }
+    __syncthreads();
+    const int nvalid = take_all ? ctl[4] : K;
+    const uint32_t prefix = thr;
+
     const bool l2 = p.t.metric == VDB_METRIC_L2;
     const float* q = p.q + (size_t)qi * p.dpad;
     const size_t rowbytes = (size_t)p.t.m * 16;
@@ -413,7 +636,7 @@ finalize_kernel(FinParams p) {
         float key = neg_inf();
         long long id = TAG_NONE;
         if (i < nvalid) {
-            const long long r = T_all[i];
+            const long long r = ST[i];
             const double sc = canon_score(p.t.rows + (size_t)r * rowbytes, q, p.t.d, p.t.dt, l2, lane);
             const float f = (float)sc;
             key = l2 ? -f : f;
@@ -425,7 +648,23 @@ finalize_kernel(FinParams p) {
     if (wave == 0) {
         // ids may legitimately equal TAG_NONE; empties are told apart by position (>= nvalid)
         // because a real entry is never worse than an empty one with the same key and id.
-        wave_bitonic_sort(RS, RT, KR, lane);
+        if (KR <= 64) {
+            // rank sort: every lane counts the entries that precede its own (broadcast LDS reads)
+            const bool has = lane < KR;
+            const float ms = has ? RS[lane] : neg_inf();
+            const long long mt = has ? RT[lane] : TAG_NONE;
+            int rank = 0;
+            for (int j = 0; j < KR; ++j) {
+                const float sj = RS[j];
+                const long long tj = RT[j];
+                rank += (better(sj, tj, ms, mt) || (sj == ms && tj == mt && j < lane)) ? 1 : 0;
+            }
+            lds_wave_sync();
+            if (has) { RS[rank] = ms; RT[rank] = mt; }
+            lds_wave_sync();
+        } else {
+            wave_bitonic_sort(RS, RT, KR, lane);
+        }
         const int cnt = nvalid < p.k ? nvalid : p.k;
         for (int i = lane; i < p.k; i += 64) {
             const bool ok = i < cnt;
@@ -435,9 +674,11 @@ finalize_kernel(FinParams p) {
         }
         if (lane == 0) {
             p.out_counts[qi] = cnt;
-            bool cert = nvalid < p.K;         // every stored row was a candidate
+            bool cert = nvalid < K;           // fewer candidates than K: every stored row is among them
             if (!cert && cnt > 0) {
-                const double theta = (double)S_all[p.K - 1];
+                // K-th best fast key: no row outside the candidate set has more
+                double theta = (double)fkey_inv(prefix);
+                if (take_all) { float mn = SS[0]; for (int i = 1; i < K; ++i) mn = fminf(mn, SS[i]); theta = (double)mn; }
                 const double bx = sqrt((double)(*p.t.max_n2)) * (1.0 + 1e-6);
                 const double bq = (double)p.qinfo[qi].bq;
                 const double u = 5.9604644775390625e-08;   // 2^-24
@@ -471,10 +712,10 @@ hipError_t launch_finalize(const TableView& t, const float* qprep, const QInfo* 
     p.out_ids = out_ids; p.out_scores = out_scores; p.out_counts = out_counts;
     p.need_exact = need_exact; p.counters = counters;
     int kr = 1; while (kr < g.K) kr <<= 1;
-    const size_t lds = (size_t)g.W * g.C * 12 + (size_t)kr * 12 + 16;
+    const size_t lds = 1088 + (size_t)g.K * 12 + (size_t)kr * 12 + (size_t)FIN_CAP * 8;
     hipError_t e = allow_lds(finalize_kernel, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)nq), dim3((unsigned)g.W * 64), lds, st, p);
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)nq), dim3(1024), lds, st, p);
     return hipGetLastError();
 }
 

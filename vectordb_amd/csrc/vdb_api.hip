@@ -75,6 +75,7 @@ struct Global {
     double cache_capacity_gb = 0.0;
     double insert_buffer_gb = 1.0;
     size_t table_bytes = 0;
+    int tune_nt = 1, tune_waves = 8, tune_bpc = 4, tune_contig = 1;
     // host-insert staging (guarded by insert_mu)
     std::mutex insert_mu;
     DevBuf stage_rows, stage_ids;
@@ -185,7 +186,8 @@ static int search_core(Table& t, int64_t nq, const float* q_dev, int k, long lon
         VDB_HIP(hipGetLastError());
         return VDB_OK;
     }
-    const SelGeom g = sel_geom(k);
+    SelGeom g = sel_geom(k);
+    if (G.tune_waves > 0 && G.tune_waves < g.W) g.W = G.tune_waves;
     const int Gx = scan_grid(tv, g, G.n_cu);
     const int64_t chunk = 256;
     const int64_t nqc = nq < chunk ? nq : chunk;
@@ -372,7 +374,12 @@ int vdb_set_option(const char* key, double value) {
     if (k == "use_blas_threshold") { if (value < 1) return fail(VDB_EINVAL, "use_blas_threshold < 1"); G.use_blas_threshold = (int)value; }
     else if (k == "cache_capacity_gb") { if (value < 0) return fail(VDB_EINVAL, "cache_capacity_gb < 0"); G.cache_capacity_gb = value; }
     else if (k == "insert_buffer_size_gb") { if (value <= 0) return fail(VDB_EINVAL, "insert_buffer_size_gb <= 0"); G.insert_buffer_gb = value; }
+    else if (k == "scan_nt") G.tune_nt = value != 0;
+    else if (k == "scan_waves") { if (value < 0 || value > 16) return fail(VDB_EINVAL, "scan_waves not in [0,16]"); G.tune_waves = (int)value; }
+    else if (k == "scan_blocks_per_cu") { if (value < 0 || value > 32) return fail(VDB_EINVAL, "scan_blocks_per_cu not in [0,32]"); G.tune_bpc = (int)value; }
+    else if (k == "scan_contiguous") G.tune_contig = value != 0;
     else return fail(VDB_EINVAL, "unknown option: " + k);
+    set_scan_tune(G.tune_nt, G.tune_waves, G.tune_bpc, G.tune_contig);
     return VDB_OK;
 }
 
@@ -665,6 +672,15 @@ int vdb_merge_records_dev(int nparts, int64_t nq, int k, int metric, const void*
     VDB_HIP(launch_merge_topk(nparts, nq, k, metric, base, stride, base + (size_t)nq * k * 8, stride,
                               base + (size_t)nq * k * 12, stride,
                               (long long*)out_ids_dev, out_scores_dev, out_counts_dev, (hipStream_t)stream));
+    return VDB_OK;
+}
+
+int vdb_bench_read_dev(const void* buf_dev, int64_t bytes, int nt, int blocks, int threads, void* stream) {
+    int rc = enter();
+    if (rc) return rc;
+    if (!buf_dev || bytes < 16 || blocks < 1 || threads < 64 || threads > 1024 || (threads & 63))
+        return fail(VDB_EINVAL, "bad argument");
+    VDB_HIP(launch_read_bw(buf_dev, bytes, nt, blocks, threads, (unsigned int*)G.d_counters, (hipStream_t)stream));
     return VDB_OK;
 }
 

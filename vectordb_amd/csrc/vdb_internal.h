@@ -46,6 +46,10 @@ struct SearchScratch {
     long long* counters;    // [2]: queries, exact fallbacks (library-wide, not per scratch)
 };
 
+void set_scan_tune(int nt, int waves, int blocks_per_cu, int contiguous);
+hipError_t launch_read_bw(const void* buf, long long bytes, int nt, int blocks, int threads,
+                          unsigned int* sink, hipStream_t st);
+
 // ---- launchers (all asynchronous on `st`) -------------------------------------------------
 hipError_t launch_prep_query(const float* q_raw, int64_t nq, int d, int dpad, int metric,
                              float* qprep, QInfo* qinfo, hipStream_t st);

@@ -138,6 +138,13 @@ class Engine:
                                              C.c_void_p(out_ids_ptr), C.c_void_p(out_scores_ptr),
                                              C.c_void_p(out_counts_ptr), C.c_void_p(stream)))
 
+    def set_option(self, key: str, value: float) -> None:
+        check(self.lib.vdb_set_option(_name(key), float(value)))
+
+    def bench_read_dev(self, buf_ptr: int, nbytes: int, nt: int, blocks: int, threads: int, stream: int = 0) -> None:
+        check(self.lib.vdb_bench_read_dev(C.c_void_p(buf_ptr), int(nbytes), int(nt), int(blocks), int(threads),
+                                          C.c_void_p(stream)))
+
     # ---- measurement
     def prof_enable(self, on: bool) -> None:
         check(self.lib.vdb_prof_enable(1 if on else 0))
