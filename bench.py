@@ -35,6 +35,7 @@ from vectordb_amd.engine import Engine             # noqa: E402
 from vectordb_amd.sharded import ShardedSearcher, gpu_backend, shard_range  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0
+MFMA_F32_PEAK_TF = 157.3          # dense fp32-input MFMA peak of one MI355X
 DTYPES = {"f32": (_lib.F32, 4), "bf16": (_lib.BF16, 2), "f16": (_lib.F16, 2)}
 METRICS = {"cosine": _lib.METRIC_COSINE, "ip": _lib.METRIC_IP, "l2": _lib.METRIC_L2}
 
@@ -150,7 +151,7 @@ def main() -> None:
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    queries_done, fallbacks = eng.stats()
+    queries_done, fallbacks, batched = eng.stats()
 
     if rank == 0:
         qps = args.steps * args.nq / elapsed
@@ -195,7 +196,18 @@ def main() -> None:
             },
             "sample_result": {"ids": [int(x) for x in last_ids[0][:3]], "scores": [float(x) for x in last_scores[0][:3]]},
         }
-        if world == 1 and args.cpu_seconds > 0:
+        if batched > 0:
+            # batched path: the dominant kernel is the fp32 MFMA GEMM over all rows (one launch per
+            # 1024-query chunk); algorithmic flops = 2 * rows * dim * queries per launch
+            nq_launch = min(args.nq, 1024)
+            flops = 2.0 * n_local * args.dim * nq_launch
+            tf = flops / avg_scan_s / 1e12 if avg_scan_s > 0 else 0.0
+            line["roofline"] = {
+                "bound": "mfma", "kernel": "gemm_thresh_kernel", "achieved": tf, "peak": MFMA_F32_PEAK_TF,
+                "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF, "traffic": None,
+                "flops_per_launch": flops, "avg_launch_ms": avg_scan_s * 1e3, "launches_timed": scan_launches,
+            }
+        if world == 1 and args.cpu_seconds > 0 and args.nq == 1:
             line["cpu_baseline"] = cpu_baseline(args.rows, args.dim, args.k, args.metric, args.cpu_seconds)
         print(json.dumps(line), flush=True)
 

@@ -145,8 +145,9 @@ int vdb_prof_read(double* scan_ms, int64_t* scan_launches);
 /* Reads `bytes` of a device buffer with the scan's access shape and no scoring: the read-bandwidth
  * ceiling the scan's achieved GB/s is compared with (tools/tune_scan.py). */
 int vdb_bench_read_dev(const void* buf_dev, int64_t bytes, int nt, int blocks, int threads, void* stream);
-/* counters since init: searches (queries), queries that needed the exact second pass */
-int vdb_stats(int64_t* queries, int64_t* exact_fallbacks);
+/* counters since init: queries answered, queries that needed the exact second pass, queries
+ * that went through the batched (MFMA GEMM) path */
+int vdb_stats(int64_t* queries, int64_t* exact_fallbacks, int64_t* batched_queries);
 
 #ifdef __cplusplus
 }

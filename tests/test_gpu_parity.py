@@ -339,3 +339,49 @@ def test_one_million_rows_properties(engine, table_name):
     ids2, sc2, _ = engine.search(table_name, q, k)
     assert np.array_equal(ids, ids2) and np.array_equal(sc.view(np.uint32), sc2.view(np.uint32))
     assert engine.stats()[1] >= 0
+
+
+# ------------------------------------------------------------------------------- batched (GEMM) path
+@pytest.mark.parametrize("metric", ["ip", "cosine", "l2"])
+@pytest.mark.parametrize("d,nq", [(96, 33), (100, 130), (768, 24)])
+def test_batched_gemm_path_parity(engine, table_name, metric, d, nq):
+    """Batches of at least engine_config.use_blas_threshold (20) queries on an fp32 table of at
+    least 65536 rows run the MFMA GEMM with the thresholded epilogue; same bar as the scan path."""
+    n = 70_000
+    rows = cases.make_rows("synth", 900 + d, n, d)
+    ids = cases.make_ids("hash", 900 + d, n)
+    q = cases.make_queries("synth", 900 + d, nq, d, rows)
+    m = cases.METRICS[metric]
+    stored = _load(engine, table_name, rows, ids, m, O.F32)
+    before = engine.stats()
+    _check(engine, table_name, stored, ids, q, 10, m)
+    after = engine.stats()
+    assert after[2] - before[2] == nq, "the batch did not take the GEMM path"
+
+
+def test_batched_gemm_path_ties_and_ordered_rows(engine, table_name):
+    """Adversarial inputs for the bootstrapped thresholds: heavy ties, and rows sorted so that
+    the best rows come last (the sample underestimates the threshold and candidate arrays
+    overflow): the flagged queries must still come back exact through the second pass."""
+    n, d, nq = 80_000, 64, 40
+    rows = cases.make_rows("ties", 77, n, d)
+    q = cases.make_queries("ties", 77, nq, d, rows)
+    order = np.argsort(rows @ q[0], kind="stable")          # ascending score for query 0
+    rows = np.ascontiguousarray(rows[order])
+    ids = cases.make_ids("hash", 77, n)
+    stored = _load(engine, table_name, rows, ids, O.IP, O.F32)
+    _check(engine, table_name, stored, ids, q, 10, O.IP)
+
+
+def test_batched_path_matches_scan_path(engine, table_name):
+    rows = cases.make_rows("synth", 5, 100_000, 128)
+    ids = cases.make_ids("index", 0, 100_000)
+    q = cases.make_queries("synth", 5, 256, 128, rows)
+    _load(engine, table_name, rows, ids, O.COSINE, O.F32)
+    a = engine.search(table_name, q, 10)
+    engine.set_option("gemm_path", 0)
+    try:
+        b = engine.search(table_name, q, 10)
+    finally:
+        engine.set_option("gemm_path", 1)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))

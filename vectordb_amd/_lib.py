@@ -46,7 +46,7 @@ SIGNATURES = {
     "vdb_bench_read_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vdb_prof_enable": (C.c_int, [C.c_int]),
     "vdb_prof_read": (C.c_int, [C.POINTER(C.c_double), _i64p]),
-    "vdb_stats": (C.c_int, [_i64p, _i64p]),
+    "vdb_stats": (C.c_int, [_i64p, _i64p, _i64p]),
 }
 
 _lib = None

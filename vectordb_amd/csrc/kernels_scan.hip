@@ -112,8 +112,9 @@ static hipError_t allow_lds(F kernel, size_t bytes) {
 // ------------------------------------------------------------------------------ prep_query
 __global__ void __launch_bounds__(64)
 prep_query_kernel(const float* __restrict__ q_raw, int d, int dpad, int metric,
-                  float* __restrict__ qprep, QInfo* __restrict__ qinfo) {
+                  float* __restrict__ qprep, QInfo* __restrict__ qinfo, int* __restrict__ need_exact) {
     const int lane = threadIdx.x;
+    if (blockIdx.x == 0 && lane == 0) need_exact[0] = 0;     // empty list of queries for the exact pass
     const float* q = q_raw + (size_t)blockIdx.x * d;
     float* out = qprep + (size_t)blockIdx.x * dpad;
     double acc = 0.0;
@@ -143,9 +144,9 @@ prep_query_kernel(const float* __restrict__ q_raw, int d, int dpad, int metric,
 }
 
 hipError_t launch_prep_query(const float* q_raw, int64_t nq, int d, int dpad, int metric,
-                             float* qprep, QInfo* qinfo, hipStream_t st) {
+                             float* qprep, QInfo* qinfo, int* need_exact, hipStream_t st) {
     hipLaunchKernelGGL(prep_query_kernel, dim3((unsigned)nq), dim3(64), 0, st,
-                       q_raw, d, dpad, metric, qprep, qinfo);
+                       q_raw, d, dpad, metric, qprep, qinfo, need_exact);
     return hipGetLastError();
 }
 
@@ -445,6 +446,11 @@ struct FinParams {
     int*             out_counts;
     int*             need_exact;
     long long*       counters;
+    // flat mode: one unsorted candidate array per query (batched path)
+    const int*       flat_cnt;   // [nq] candidates appended (may exceed flat_cap: the excess was lost)
+    int              flat_cap;
+    const float*     flat_tau;   // [nq] every row that is not a candidate has a fast key <= tau
+    const int*       flat_lost;  // [nq]
 };
 
 __device__ __forceinline__ int pow2_ceil_dev(int v) { int p = 1; while (p < v) p <<= 1; return p; }
@@ -535,6 +541,7 @@ constexpr int FIN_CAP = 2048;     // survivors of the pre-filter kept in LDS
 // head is a lower bound of the K-th best key overall; everything below it is dropped with one
 // compare per candidate, and the exact K best are radix-selected among the few survivors.  The
 // K rows are then re-scored canonically, sorted by (score, id) and the answer is certified.
+template <bool FLAT>
 __global__ void __launch_bounds__(1024)
 finalize_kernel(FinParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -554,9 +561,14 @@ finalize_kernel(FinParams p) {
     int*       VI   = (int*)(VS + FIN_CAP);             // FIN_CAP survivor positions
 
     const int qi = blockIdx.x;
-    const long long M = (long long)p.G * K;
-    const float*     gs = p.cand_s + (size_t)qi * M;
-    const long long* gt = p.cand_t + (size_t)qi * M;
+    long long M = (long long)p.G * K;
+    size_t qoff = (size_t)qi * M;
+    if (FLAT) {
+        M = p.flat_cnt[qi] < p.flat_cap ? p.flat_cnt[qi] : p.flat_cap;
+        qoff = (size_t)qi * p.flat_cap;
+    }
+    const float*     gs = p.cand_s + qoff;
+    const long long* gt = p.cand_t + qoff;
 
     if (tid < 16) ctl[tid] = 0;
     __syncthreads();
@@ -566,7 +578,7 @@ finalize_kernel(FinParams p) {
 
     // (A) lower bound from the list heads
     uint32_t lb = 0;
-    if (p.G > K) {
+    if (!FLAT && p.G > K) {
         int nd;
         bool all;
         if (p.G <= 8 * nth) {
@@ -581,7 +593,7 @@ finalize_kernel(FinParams p) {
         __syncthreads();
     }
     // (B) survivors of the lower bound, appended wave by wave
-    for (long long i0 = 0; i0 < M; i0 += (long long)nth * 32) {
+    for (long long i0 = 0; !FLAT && i0 < M; i0 += (long long)nth * 32) {
         float v[32];                             // 32 loads in flight: one round trip per 32*nth candidates
 #pragma unroll
         for (int u = 0; u < 32; ++u) { const long long i = i0 + (long long)u * nth + tid; v[u] = (i < M) ? gs[i] : neg_inf(); }
@@ -601,7 +613,7 @@ finalize_kernel(FinParams p) {
     }
     __syncthreads();
     const int S = ctl[5];
-    if (S <= FIN_CAP) {
+    if (!FLAT && S <= FIN_CAP) {
         // (C) exact K best among the survivors
         take_all = select_kth([&](long long j, int) { return VS[j]; }, (long long)S, K, hist, ctl, thr, need);
         for (int j = tid; j < S; j += nth) {
@@ -674,11 +686,14 @@ finalize_kernel(FinParams p) {
         }
         if (lane == 0) {
             p.out_counts[qi] = cnt;
-            bool cert = nvalid < K;           // fewer candidates than K: every stored row is among them
-            if (!cert && cnt > 0) {
-                // K-th best fast key: no row outside the candidate set has more
+            // lists mode with fewer candidates than K: every stored row is among them
+            bool cert = !FLAT && nvalid < K;
+            const bool usable = !FLAT || (p.flat_lost[qi] == 0 && (long long)cnt == (p.t.n < p.k ? p.t.n : (long long)p.k));
+            if (!cert && cnt > 0 && usable) {
+                // theta: no row outside the candidate set has a larger fast key
                 double theta = (double)fkey_inv(prefix);
-                if (take_all) { float mn = SS[0]; for (int i = 1; i < K; ++i) mn = fminf(mn, SS[i]); theta = (double)mn; }
+                if (take_all) { float mn = SS[0]; for (int i = 1; i < nvalid; ++i) mn = fminf(mn, SS[i]); theta = (double)mn; }
+                if (FLAT) { const double tau = (double)p.flat_tau[qi]; if (take_all || tau > theta) theta = tau; }
                 const double bx = sqrt((double)(*p.t.max_n2)) * (1.0 + 1e-6);
                 const double bq = (double)p.qinfo[qi].bq;
                 const double u = 5.9604644775390625e-08;   // 2^-24
@@ -694,7 +709,7 @@ finalize_kernel(FinParams p) {
                     cert = dist_k * (1.0 + 8.0 * u) + 1e-37 < bound;
                 }
             }
-            p.need_exact[qi] = cert ? 0 : 1;
+            if (!cert) { const int pos = atomicAdd(&p.need_exact[0], 1); p.need_exact[1 + pos] = qi; }
             atomicAdd((unsigned long long*)&p.counters[0], 1ull);
         }
     }
@@ -711,11 +726,33 @@ hipError_t launch_finalize(const TableView& t, const float* qprep, const QInfo* 
     p.cand_s = cand_s; p.cand_t = cand_t;
     p.out_ids = out_ids; p.out_scores = out_scores; p.out_counts = out_counts;
     p.need_exact = need_exact; p.counters = counters;
+    p.flat_cnt = nullptr; p.flat_cap = 0; p.flat_tau = nullptr; p.flat_lost = nullptr;
     int kr = 1; while (kr < g.K) kr <<= 1;
     const size_t lds = 1088 + (size_t)g.K * 12 + (size_t)kr * 12 + (size_t)FIN_CAP * 8;
-    hipError_t e = allow_lds(finalize_kernel, lds);
+    hipError_t e = allow_lds(finalize_kernel<false>, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)nq), dim3(1024), lds, st, p);
+    hipLaunchKernelGGL((finalize_kernel<false>), dim3((unsigned)nq), dim3(1024), lds, st, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_finalize_flat(const TableView& t, const float* qprep, const QInfo* qinfo, int64_t nq,
+                                int dpad, const SelGeom& g, int k,
+                                const float* cand_s, const long long* cand_t, const int* cnt, int cap,
+                                const float* tau, const int* lost,
+                                long long* out_ids, float* out_scores, int* out_counts,
+                                int* need_exact, long long* counters, hipStream_t st) {
+    FinParams p;
+    p.t = t; p.q = qprep; p.qinfo = qinfo; p.dpad = dpad;
+    p.K = g.K; p.C = g.C; p.G = 0; p.k = k;
+    p.cand_s = cand_s; p.cand_t = cand_t;
+    p.out_ids = out_ids; p.out_scores = out_scores; p.out_counts = out_counts;
+    p.need_exact = need_exact; p.counters = counters;
+    p.flat_cnt = cnt; p.flat_cap = cap; p.flat_tau = tau; p.flat_lost = lost;
+    int kr = 1; while (kr < g.K) kr <<= 1;
+    const size_t lds = 1088 + (size_t)g.K * 12 + (size_t)kr * 12 + (size_t)FIN_CAP * 8;
+    hipError_t e = allow_lds(finalize_kernel<true>, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((finalize_kernel<true>), dim3((unsigned)nq), dim3(1024), lds, st, p);
     return hipGetLastError();
 }
 
@@ -735,34 +772,39 @@ struct ExactParams {
     int          G;
 };
 
+// need_exact[0] = number of flagged queries, need_exact[1..] = their indices (written by the
+// finalize kernels, reset by prep_query).  Both kernels run on a small fixed grid and loop over
+// the flagged list, so an empty list costs one early-exit launch however many queries there are.
 __global__ void __launch_bounds__(1024)
 exact_scan_kernel(ExactParams p) {
-    const int qi = blockIdx.y;
-    if (p.need_exact[qi] == 0) return;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int W = blockDim.x >> 6;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float*     S_all = (float*)smem;
     long long* T_all = (long long*)(smem + (size_t)W * p.C * sizeof(float));
     const bool l2 = p.t.metric == VDB_METRIC_L2;
-    const float* q = p.q + (size_t)qi * p.dpad;
     const size_t rowbytes = (size_t)p.t.m * 16;
-
-    WaveSel sel;
-    sel.init(S_all + (size_t)wave * p.C, T_all + (size_t)wave * p.C, p.C, p.K, lane);
-    const long long TW = (long long)gridDim.x * W;
-    for (long long r = (long long)blockIdx.x * W + wave; r < p.t.n; r += TW) {
-        const double sc = canon_score(p.t.rows + (size_t)r * rowbytes, q, p.t.d, p.t.dt, l2, lane);
-        const float f = (float)sc;
-        const float key = l2 ? -f : f;
-        const long long id = p.t.ids[r];
-        const bool pass = (lane == 0) && better(key, id, sel.thr_s, sel.thr_t);
-        sel.push(pass, key, id, lane);
-    }
-    block_merge(sel, S_all, T_all, W, wave, lane);
-    if (wave == 0) {
-        const size_t o = ((size_t)qi * gridDim.x + blockIdx.x) * p.K;
-        for (int i = lane; i < p.K; i += 64) { p.cand_s[o + i] = S_all[i]; p.cand_t[o + i] = T_all[i]; }
+    const int nflag = p.need_exact[0];
+    for (int f = blockIdx.y; f < nflag; f += gridDim.y) {
+        const int qi = p.need_exact[1 + f];
+        const float* q = p.q + (size_t)qi * p.dpad;
+        __syncthreads();                       // the previous query's lists have been written out
+        WaveSel sel;
+        sel.init(S_all + (size_t)wave * p.C, T_all + (size_t)wave * p.C, p.C, p.K, lane);
+        const long long TW = (long long)gridDim.x * W;
+        for (long long r = (long long)blockIdx.x * W + wave; r < p.t.n; r += TW) {
+            const double sc = canon_score(p.t.rows + (size_t)r * rowbytes, q, p.t.d, p.t.dt, l2, lane);
+            const float fs = (float)sc;
+            const float key = l2 ? -fs : fs;
+            const long long id = p.t.ids[r];
+            const bool pass = (lane == 0) && better(key, id, sel.thr_s, sel.thr_t);
+            sel.push(pass, key, id, lane);
+        }
+        block_merge(sel, S_all, T_all, W, wave, lane);
+        if (wave == 0) {
+            const size_t o = ((size_t)f * gridDim.x + blockIdx.x) * p.K;
+            for (int i = lane; i < p.K; i += 64) { p.cand_s[o + i] = S_all[i]; p.cand_t[o + i] = T_all[i]; }
+        }
     }
 }
 
@@ -770,41 +812,42 @@ exact_scan_kernel(ExactParams p) {
 // therefore merges with its own loop that keeps every entry of the first min(K, rows) per block.
 __global__ void __launch_bounds__(1024)
 exact_finalize_kernel(ExactParams p) {
-    const int qi = blockIdx.x;
-    if (p.need_exact[qi] == 0) return;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int W = blockDim.x >> 6;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float*     S_all = (float*)smem;
     long long* T_all = (long long*)(smem + (size_t)W * p.C * sizeof(float));
     const bool l2 = p.t.metric == VDB_METRIC_L2;
-
-    const long long ncand = (long long)p.G * p.K;
-    const float* gs = p.cand_s + (size_t)qi * ncand;
-    const long long* gt = p.cand_t + (size_t)qi * ncand;
-    WaveSel sel;
-    sel.init(S_all + (size_t)wave * p.C, T_all + (size_t)wave * p.C, p.C, p.K, lane);
-    for (long long base = (long long)wave * 64; base < ncand; base += (long long)W * 64) {
-        const long long i = base + lane;
-        float key = neg_inf();
-        long long tag = TAG_NONE;
-        if (i < ncand) { key = gs[i]; tag = gt[i]; }
-        const bool pass = (i < ncand) && better(key, tag, sel.thr_s, sel.thr_t);
-        sel.push(pass, key, tag, lane);
-    }
-    block_merge(sel, S_all, T_all, W, wave, lane);
-    if (wave == 0) {
-        const long long cnt = p.t.n < p.k ? p.t.n : p.k;
-        for (int i = lane; i < p.k; i += 64) {
-            const bool ok = i < cnt;
-            p.out_ids[(size_t)qi * p.k + i] = ok ? T_all[i] : -1ll;
-            const float key = S_all[i];
-            p.out_scores[(size_t)qi * p.k + i] = ok ? (l2 ? -key : key) : (l2 ? __builtin_huge_valf() : neg_inf());
+    const int nflag = p.need_exact[0];
+    for (int f = blockIdx.x; f < nflag; f += gridDim.x) {
+        const int qi = p.need_exact[1 + f];
+        const long long ncand = (long long)p.G * p.K;
+        const float* gs = p.cand_s + (size_t)f * ncand;
+        const long long* gt = p.cand_t + (size_t)f * ncand;
+        __syncthreads();
+        WaveSel sel;
+        sel.init(S_all + (size_t)wave * p.C, T_all + (size_t)wave * p.C, p.C, p.K, lane);
+        for (long long base = (long long)wave * 64; base < ncand; base += (long long)W * 64) {
+            const long long i = base + lane;
+            float key = neg_inf();
+            long long tag = TAG_NONE;
+            if (i < ncand) { key = gs[i]; tag = gt[i]; }
+            const bool pass = (i < ncand) && better(key, tag, sel.thr_s, sel.thr_t);
+            sel.push(pass, key, tag, lane);
         }
-        if (lane == 0) {
-            p.out_counts[qi] = (int)cnt;
-            p.need_exact[qi] = 0;
-            atomicAdd((unsigned long long*)&p.counters[1], 1ull);
+        block_merge(sel, S_all, T_all, W, wave, lane);
+        if (wave == 0) {
+            const long long cnt = p.t.n < p.k ? p.t.n : p.k;
+            for (int i = lane; i < p.k; i += 64) {
+                const bool ok = i < cnt;
+                p.out_ids[(size_t)qi * p.k + i] = ok ? T_all[i] : -1ll;
+                const float key = S_all[i];
+                p.out_scores[(size_t)qi * p.k + i] = ok ? (l2 ? -key : key) : (l2 ? __builtin_huge_valf() : neg_inf());
+            }
+            if (lane == 0) {
+                p.out_counts[qi] = (int)cnt;
+                atomicAdd((unsigned long long*)&p.counters[1], 1ull);
+            }
         }
     }
 }
@@ -819,11 +862,12 @@ hipError_t launch_exact(const TableView& t, const float* qprep, int64_t nq, int 
     p.out_ids = out_ids; p.out_scores = out_scores; p.out_counts = out_counts;
     p.need_exact = need_exact; p.counters = counters; p.G = G;
     const size_t lds = (size_t)g.W * g.C * 12;
-    hipLaunchKernelGGL(exact_scan_kernel, dim3((unsigned)G, (unsigned)nq), dim3((unsigned)g.W * 64),
-                       lds, st, p);
+    const unsigned gy = (unsigned)(nq < 8 ? nq : 8);
+    hipLaunchKernelGGL(exact_scan_kernel, dim3((unsigned)G, gy), dim3((unsigned)g.W * 64), lds, st, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(exact_finalize_kernel, dim3((unsigned)nq), dim3((unsigned)g.W * 64), lds, st, p);
+    const unsigned gf = (unsigned)(nq < 64 ? nq : 64);
+    hipLaunchKernelGGL(exact_finalize_kernel, dim3(gf), dim3((unsigned)g.W * 64), lds, st, p);
     return hipGetLastError();
 }
 

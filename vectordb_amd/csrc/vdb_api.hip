@@ -42,6 +42,7 @@ struct Workspace {
     hipEvent_t  done = nullptr;          // recorded after the last call's work
     bool        used = false;
     DevBuf qprep, qinfo, cand_s, cand_t, need_exact;      // search scratch
+    DevBuf small;                                         // batched path: cnt | lost | thr0 | thr1
     DevBuf q_raw, o_ids, o_scores, o_counts;              // staging of the host entry point
 };
 
@@ -75,12 +76,13 @@ struct Global {
     double cache_capacity_gb = 0.0;
     double insert_buffer_gb = 1.0;
     size_t table_bytes = 0;
-    int tune_nt = 1, tune_waves = 8, tune_bpc = 4, tune_contig = 1;
+    int tune_nt = 1, tune_waves = 8, tune_bpc = 4, tune_contig = 1, tune_gemm = 1;
     // host-insert staging (guarded by insert_mu)
     std::mutex insert_mu;
     DevBuf stage_rows, stage_ids;
     hipStream_t insert_stream = nullptr;
     // profiling
+    std::atomic<long long> batched_queries{0};
     std::atomic<int> prof_on{0};
     std::mutex prof_mu;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
@@ -173,6 +175,145 @@ __global__ void fill_empty_kernel(long long* ids, float* scores, int* counts, lo
 }
 
 // ------------------------------------------------------------------------------ search core
+struct ProfScope {
+    // brackets one kernel launch with HIP events on its stream when profiling is enabled
+    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    bool on = false;
+    int begin(hipStream_t st) {
+        on = G.prof_on.load() != 0;
+        if (!on) return VDB_OK;
+        {
+            std::lock_guard<std::mutex> lk(G.prof_mu);
+            if (!G.prof_pool.empty()) { ev = G.prof_pool.back(); G.prof_pool.pop_back(); }
+        }
+        if (!ev.first) {
+            VDB_HIP(hipEventCreate(&ev.first));
+            VDB_HIP(hipEventCreate(&ev.second));
+        }
+        VDB_HIP(hipEventRecord(ev.first, st));
+        return VDB_OK;
+    }
+    int end(hipStream_t st) {
+        if (!on) return VDB_OK;
+        VDB_HIP(hipEventRecord(ev.second, st));
+        std::lock_guard<std::mutex> lk(G.prof_mu);
+        G.prof_events.push_back(ev);
+        return VDB_OK;
+    }
+};
+
+static const int GEMM_CAP = 8192;          // candidate slots per query on the batched path
+static const double GEMM_TARGET = 2048.0;  // candidates per query each pass aims for
+
+// Per-query path: one bandwidth-bound scan of the table per query.
+static int search_scan_path(const TableView& tv, const SelGeom& g, int dpad, int64_t nq, const float* q_dev,
+                            int k, long long* out_ids, float* out_scores, int* out_counts,
+                            hipStream_t st, Workspace& ws) {
+    const int Gx = scan_grid(tv, g, G.n_cu);
+    const int64_t chunk = 256;
+    const int64_t nqc = nq < chunk ? nq : chunk;
+    int rc;
+    if ((rc = ensure(ws.qprep, (size_t)nqc * dpad * sizeof(float), ws.last_stream))) return rc;
+    if ((rc = ensure(ws.qinfo, (size_t)nqc * sizeof(QInfo), ws.last_stream))) return rc;
+    if ((rc = ensure(ws.cand_s, (size_t)nqc * Gx * g.K * sizeof(float), ws.last_stream))) return rc;
+    if ((rc = ensure(ws.cand_t, (size_t)nqc * Gx * g.K * sizeof(long long), ws.last_stream))) return rc;
+    if ((rc = ensure(ws.need_exact, (size_t)(nqc + 1) * sizeof(int), ws.last_stream))) return rc;
+    for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
+        const int64_t nqi = nq - q0 < chunk ? nq - q0 : chunk;
+        float* qprep = (float*)ws.qprep.p;
+        QInfo* qinfo = (QInfo*)ws.qinfo.p;
+        float* cs = (float*)ws.cand_s.p;
+        long long* ct = (long long*)ws.cand_t.p;
+        int* ne = (int*)ws.need_exact.p;
+        VDB_HIP(launch_prep_query(q_dev + (size_t)q0 * tv.d, nqi, tv.d, dpad, tv.metric, qprep, qinfo, ne, st));
+        ProfScope prof;
+        if ((rc = prof.begin(st))) return rc;
+        VDB_HIP(launch_scan(tv, qprep, nqi, dpad, g, Gx, cs, ct, st));
+        if ((rc = prof.end(st))) return rc;
+        VDB_HIP(launch_finalize(tv, qprep, qinfo, nqi, dpad, g, Gx, k, cs, ct,
+                                out_ids + (size_t)q0 * k, out_scores + (size_t)q0 * k, out_counts + q0,
+                                ne, G.d_counters, st));
+        VDB_HIP(launch_exact(tv, qprep, nqi, dpad, g, Gx, k, cs, ct,
+                             out_ids + (size_t)q0 * k, out_scores + (size_t)q0 * k, out_counts + q0,
+                             ne, G.d_counters, st));
+    }
+    return VDB_OK;
+}
+
+// Batched path (fp32 tables): MFMA GEMM with a thresholded epilogue, thresholds bootstrapped by
+// two smaller passes (exact top-K of the first rows, then a strided sample of the row tiles).
+static int search_gemm_path(const TableView& tv, const SelGeom& g, int dpad, int64_t nq, const float* q_dev,
+                            int k, long long* out_ids, float* out_scores, int* out_counts,
+                            hipStream_t st, Workspace& ws) {
+    const int K = g.K;
+    const long long ntiles = (tv.n + 127) / 128;
+    long long tiles1 = (long long)std::ceil((double)tv.n * K / GEMM_TARGET / 128.0);
+    if (tiles1 < 8) tiles1 = 8;
+    if (tiles1 > ntiles) tiles1 = ntiles;
+    long long stride1 = ntiles / tiles1;
+    if (stride1 < 1) stride1 = 1;
+    tiles1 = ntiles / stride1;
+    long long n0 = (long long)((double)tiles1 * 128.0 * K / GEMM_TARGET);
+    if (n0 < 1024) n0 = 1024;
+    if (n0 > 8192) n0 = 8192;
+    if (n0 > tv.n) n0 = tv.n;
+    TableView tv0 = tv;
+    tv0.n = n0;
+    const int G0 = scan_grid(tv0, g, G.n_cu);
+    const int Gx = scan_grid(tv, g, G.n_cu);
+    const int64_t chunk = 1024;
+    const int64_t nqc = nq < chunk ? nq : chunk;
+    size_t slots = (size_t)nqc * GEMM_CAP;
+    if ((size_t)nqc * G0 * K > slots) slots = (size_t)nqc * G0 * K;
+    if ((size_t)nqc * Gx * K > slots) slots = (size_t)nqc * Gx * K;
+    int rc;
+    if ((rc = ensure(ws.qprep, (size_t)nqc * dpad * sizeof(float), ws.last_stream))) return rc;
+    if ((rc = ensure(ws.qinfo, (size_t)nqc * sizeof(QInfo), ws.last_stream))) return rc;
+    if ((rc = ensure(ws.cand_s, slots * sizeof(float), ws.last_stream))) return rc;
+    if ((rc = ensure(ws.cand_t, slots * sizeof(long long), ws.last_stream))) return rc;
+    if ((rc = ensure(ws.need_exact, (size_t)(nqc + 1) * sizeof(int), ws.last_stream))) return rc;
+    if ((rc = ensure(ws.small, (size_t)nqc * 16, ws.last_stream))) return rc;
+    for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
+        const int nqi = (int)(nq - q0 < chunk ? nq - q0 : chunk);
+        float* qprep = (float*)ws.qprep.p;
+        QInfo* qinfo = (QInfo*)ws.qinfo.p;
+        float* cs = (float*)ws.cand_s.p;
+        long long* ct = (long long*)ws.cand_t.p;
+        int* ne = (int*)ws.need_exact.p;
+        int* cnt = (int*)ws.small.p;
+        int* lost = cnt + nqc;
+        float* thr0 = (float*)(lost + nqc);
+        float* thr1 = thr0 + nqc;
+        VDB_HIP(launch_prep_query(q_dev + (size_t)q0 * tv.d, nqi, tv.d, dpad, tv.metric, qprep, qinfo, ne, st));
+        // pass 0: every score of the first n0 (<= GEMM_CAP) rows is kept; thr0 = K-th best of them
+        VDB_HIP(hipMemsetAsync(cnt, 0, (size_t)nqc * 8, st));
+        VDB_HIP(hipMemsetD32Async((hipDeviceptr_t)thr1, (int)0xff800000, (size_t)nqc, st));      // -inf
+        VDB_HIP(launch_gemm_thresh(tv0, qprep, nqi, dpad, thr1, 0, 1, (n0 + 127) / 128, cs, ct, cnt, lost, GEMM_CAP, G.n_cu, st));
+        VDB_HIP(launch_kth_threshold(cs, GEMM_CAP, cnt, 0, GEMM_CAP, K, nullptr, thr0, nqi, st));
+        const float* tau = thr0;
+        if (stride1 > 1) {
+            // pass 1: every stride1-th row tile -> thr1
+            VDB_HIP(hipMemsetAsync(cnt, 0, (size_t)nqc * 8, st));
+            VDB_HIP(launch_gemm_thresh(tv, qprep, nqi, dpad, thr0, 0, stride1, tiles1, cs, ct, cnt, lost, GEMM_CAP, G.n_cu, st));
+            VDB_HIP(launch_kth_threshold(cs, GEMM_CAP, cnt, 0, GEMM_CAP, K, thr0, thr1, nqi, st));
+            tau = thr1;
+        }
+        // pass 2: all row tiles
+        VDB_HIP(hipMemsetAsync(cnt, 0, (size_t)nqc * 8, st));
+        ProfScope prof;
+        if ((rc = prof.begin(st))) return rc;
+        VDB_HIP(launch_gemm_thresh(tv, qprep, nqi, dpad, tau, 0, 1, ntiles, cs, ct, cnt, lost, GEMM_CAP, G.n_cu, st));
+        if ((rc = prof.end(st))) return rc;
+        VDB_HIP(launch_finalize_flat(tv, qprep, qinfo, nqi, dpad, g, k, cs, ct, cnt, GEMM_CAP, tau, lost,
+                                     out_ids + (size_t)q0 * k, out_scores + (size_t)q0 * k, out_counts + q0,
+                                     ne, G.d_counters, st));
+        VDB_HIP(launch_exact(tv, qprep, nqi, dpad, g, Gx, k, cs, ct,
+                             out_ids + (size_t)q0 * k, out_scores + (size_t)q0 * k, out_counts + q0,
+                             ne, G.d_counters, st));
+    }
+    return VDB_OK;
+}
+
 static int search_core(Table& t, int64_t nq, const float* q_dev, int k, long long* out_ids,
                        float* out_scores, int* out_counts, hipStream_t st, Workspace& ws) {
     TableView tv;
@@ -188,50 +329,12 @@ static int search_core(Table& t, int64_t nq, const float* q_dev, int k, long lon
     }
     SelGeom g = sel_geom(k);
     if (G.tune_waves > 0 && G.tune_waves < g.W) g.W = G.tune_waves;
-    const int Gx = scan_grid(tv, g, G.n_cu);
-    const int64_t chunk = 256;
-    const int64_t nqc = nq < chunk ? nq : chunk;
-    int rc;
-    if ((rc = ensure(ws.qprep, (size_t)nqc * t.dpad * sizeof(float), ws.last_stream))) return rc;
-    if ((rc = ensure(ws.qinfo, (size_t)nqc * sizeof(QInfo), ws.last_stream))) return rc;
-    if ((rc = ensure(ws.cand_s, (size_t)nqc * Gx * g.K * sizeof(float), ws.last_stream))) return rc;
-    if ((rc = ensure(ws.cand_t, (size_t)nqc * Gx * g.K * sizeof(long long), ws.last_stream))) return rc;
-    if ((rc = ensure(ws.need_exact, (size_t)nqc * sizeof(int), ws.last_stream))) return rc;
-
-    for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
-        const int64_t nqi = nq - q0 < chunk ? nq - q0 : chunk;
-        float* qprep = (float*)ws.qprep.p;
-        QInfo* qinfo = (QInfo*)ws.qinfo.p;
-        float* cs = (float*)ws.cand_s.p;
-        long long* ct = (long long*)ws.cand_t.p;
-        int* ne = (int*)ws.need_exact.p;
-        VDB_HIP(launch_prep_query(q_dev + (size_t)q0 * t.dim, nqi, (int)t.dim, t.dpad, t.metric, qprep, qinfo, st));
-
-        std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
-        const bool prof = G.prof_on.load() != 0;
-        if (prof) {
-            std::lock_guard<std::mutex> lk(G.prof_mu);
-            if (!G.prof_pool.empty()) { ev = G.prof_pool.back(); G.prof_pool.pop_back(); }
-        }
-        if (prof && !ev.first) {
-            VDB_HIP(hipEventCreate(&ev.first));
-            VDB_HIP(hipEventCreate(&ev.second));
-        }
-        if (prof) VDB_HIP(hipEventRecord(ev.first, st));
-        VDB_HIP(launch_scan(tv, qprep, nqi, t.dpad, g, Gx, cs, ct, st));
-        if (prof) {
-            VDB_HIP(hipEventRecord(ev.second, st));
-            std::lock_guard<std::mutex> lk(G.prof_mu);
-            G.prof_events.push_back(ev);
-        }
-        VDB_HIP(launch_finalize(tv, qprep, qinfo, nqi, t.dpad, g, Gx, k, cs, ct,
-                                out_ids + (size_t)q0 * k, out_scores + (size_t)q0 * k, out_counts + q0,
-                                ne, G.d_counters, st));
-        VDB_HIP(launch_exact(tv, qprep, nqi, t.dpad, g, Gx, k, cs, ct,
-                             out_ids + (size_t)q0 * k, out_scores + (size_t)q0 * k, out_counts + q0,
-                             ne, G.d_counters, st));
-    }
-    return VDB_OK;
+    // engine_config.use_blas_threshold: batches at least this large take the GEMM path
+    const bool gemm = nq >= G.use_blas_threshold && t.dtype == VDB_F32 && tv.n >= 65536 && g.K <= 256 &&
+                      G.tune_gemm != 0;
+    if (gemm) G.batched_queries += nq;
+    if (gemm) return search_gemm_path(tv, g, t.dpad, nq, q_dev, k, out_ids, out_scores, out_counts, st, ws);
+    return search_scan_path(tv, g, t.dpad, nq, q_dev, k, out_ids, out_scores, out_counts, st, ws);
 }
 
 // ------------------------------------------------------------------------------ table storage
@@ -350,7 +453,7 @@ int vdb_shutdown(void) {
     std::lock_guard<std::mutex> lk(G.mu);
     for (auto& w : G.free_ws) {
         for (DevBuf* b : {&w->qprep, &w->qinfo, &w->cand_s, &w->cand_t, &w->need_exact, &w->q_raw,
-                          &w->o_ids, &w->o_scores, &w->o_counts})
+                          &w->o_ids, &w->o_scores, &w->o_counts, &w->small})
             if (b->p) (void)hipFree(b->p);
         if (w->stream) (void)hipStreamDestroy(w->stream);
         if (w->done) (void)hipEventDestroy(w->done);
@@ -378,6 +481,7 @@ int vdb_set_option(const char* key, double value) {
     else if (k == "scan_waves") { if (value < 0 || value > 16) return fail(VDB_EINVAL, "scan_waves not in [0,16]"); G.tune_waves = (int)value; }
     else if (k == "scan_blocks_per_cu") { if (value < 0 || value > 32) return fail(VDB_EINVAL, "scan_blocks_per_cu not in [0,32]"); G.tune_bpc = (int)value; }
     else if (k == "scan_contiguous") G.tune_contig = value != 0;
+    else if (k == "gemm_path") G.tune_gemm = value != 0;
     else return fail(VDB_EINVAL, "unknown option: " + k);
     set_scan_tune(G.tune_nt, G.tune_waves, G.tune_bpc, G.tune_contig);
     return VDB_OK;
@@ -711,7 +815,7 @@ int vdb_prof_read(double* scan_ms, int64_t* scan_launches) {
     return VDB_OK;
 }
 
-int vdb_stats(int64_t* queries, int64_t* exact_fallbacks) {
+int vdb_stats(int64_t* queries, int64_t* exact_fallbacks, int64_t* batched_queries) {
     int rc = enter();
     if (rc) return rc;
     long long h[2] = {0, 0};
@@ -719,6 +823,7 @@ int vdb_stats(int64_t* queries, int64_t* exact_fallbacks) {
     VDB_HIP(hipMemcpy(h, G.d_counters, sizeof(h), hipMemcpyDeviceToHost));
     if (queries) *queries = h[0];
     if (exact_fallbacks) *exact_fallbacks = h[1];
+    if (batched_queries) *batched_queries = G.batched_queries.load();
     return VDB_OK;
 }
 

@@ -51,8 +51,10 @@ hipError_t launch_read_bw(const void* buf, long long bytes, int nt, int blocks, 
                           unsigned int* sink, hipStream_t st);
 
 // ---- launchers (all asynchronous on `st`) -------------------------------------------------
+// Also empties the list of queries flagged for the exact pass: need_exact[0] = count,
+// need_exact[1..] = query indices (nq + 1 ints).
 hipError_t launch_prep_query(const float* q_raw, int64_t nq, int d, int dpad, int metric,
-                             float* qprep, QInfo* qinfo, hipStream_t st);
+                             float* qprep, QInfo* qinfo, int* need_exact, hipStream_t st);
 
 // Fast pass: fp32 scoring of every row, top-K candidates per (query, block).
 // Returns the grid width G through *out_G (cand arrays must hold nq*G*K entries; use scan_grid()).
@@ -66,6 +68,26 @@ hipError_t launch_finalize(const TableView& t, const float* qprep, const QInfo* 
                            const float* cand_s, const long long* cand_t,
                            long long* out_ids, float* out_scores, int* out_counts,
                            int* need_exact, long long* counters, hipStream_t st);
+
+// Same for the batched path: one unsorted candidate array of `cap` slots per query, `cnt[q]`
+// appended, every non-candidate row known to have a fast key <= tau[q].
+hipError_t launch_finalize_flat(const TableView& t, const float* qprep, const QInfo* qinfo, int64_t nq,
+                                int dpad, const SelGeom& g, int k,
+                                const float* cand_s, const long long* cand_t, const int* cnt, int cap,
+                                const float* tau, const int* lost,
+                                long long* out_ids, float* out_scores, int* out_counts,
+                                int* need_exact, long long* counters, hipStream_t st);
+
+// Batched path: MFMA GEMM over the row tiles tile0 + t*tile_stride (t < ntiles) of 128 rows each,
+// appending every score above thr[q] to query q's candidate array.
+hipError_t launch_gemm_thresh(const TableView& t, const float* qprep, int nq, int dpad, const float* thr,
+                              long long tile0, long long tile_stride, long long ntiles,
+                              float* cand_s, long long* cand_t, int* cnt, int* lost, int cap,
+                              int n_cu, hipStream_t st);
+// thr_out[q] = max(thr_in[q], K-th best key among query q's candidates); candidates of query q start
+// at cand_s + q*stride and number cnt[q] (capped at cap), or count_all when cnt is null.
+hipError_t launch_kth_threshold(const float* cand_s, long long stride, const int* cnt, long long count_all,
+                                int cap, int K, const float* thr_in, float* thr_out, int nq, hipStream_t st);
 
 // Exact second pass for the queries whose fast pass could not be certified.
 hipError_t launch_exact(const TableView& t, const float* qprep, int64_t nq, int dpad,

@@ -154,10 +154,11 @@ class Engine:
         check(self.lib.vdb_prof_read(C.byref(ms), C.byref(n)))
         return float(ms.value), int(n.value)
 
-    def stats(self) -> Tuple[int, int]:
-        q, f = C.c_int64(0), C.c_int64(0)
-        check(self.lib.vdb_stats(C.byref(q), C.byref(f)))
-        return int(q.value), int(f.value)
+    def stats(self) -> Tuple[int, int, int]:
+        """(queries answered, queries that took the exact second pass, queries on the batched path)"""
+        q, f, b = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        check(self.lib.vdb_stats(C.byref(q), C.byref(f), C.byref(b)))
+        return int(q.value), int(f.value), int(b.value)
 
     def shutdown(self) -> None:
         check(self.lib.vdb_shutdown())
