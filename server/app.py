@@ -1,0 +1,184 @@
+"""HTTP service with the reference's routes (/root/reference/app.py:194-435) over the in-process
+MI355X engine.  Same wire format (curl-com.txt:1: PUT, JSON body {"name", "vector"}, query argument
+`dbname`, port 5001) and the same flow per request:
+
+  PUT /insert       hash the vector, record (hash, asset); a new hash also stores the vector
+  PUT /lookup       exact matches by hash first (distance 0), then the engine's top-k, each hit
+                    mapped back to its asset ids
+  PUT /lookupexact  asset ids of the vector's hash
+  GET /createdb     ?dbname=&dimensions=  (+ optional metric=ip|l2|cosine, dtype=f32|bf16|f16)
+  GET /deletedb, /checkintegrity, /
+
+The engine client is the `milvus` module of this repository (the reference's import line,
+app.py:3, unchanged); the relational side is server/metastore.py instead of a Postgres server.
+
+Differences from the reference, on purpose:
+  * /lookup returns each hit's own asset ids.  The reference appends the exact-match list to
+    every hit (app.py:431 uses `assets_ids` where `asset_ids` was meant); set
+    VDB_COMPAT_LOOKUP_BUG=1 to reproduce that output.
+  * /lookup accepts optional ?k= (default 10, as hard-coded at app.py:426) and a JSON body with
+    "vectors": [[...], ...] for a batch (answers a list of result lists).
+  * database names are validated instead of being concatenated into SQL.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import threading
+
+from flask import Flask, request
+
+from milvus import IndexType, MetricType, Milvus
+from server.metastore import MetaStore, MetaStoreError
+from vectordb_amd.hashing import hash_vector
+
+_HOST = "127.0.0.1"       # kept for the connect() call; the engine runs in this process
+_PORT = "19530"
+_INDEX_FILE_SIZE = 32
+_METRICS = {"ip": MetricType.IP, "l2": MetricType.L2, "cosine": MetricType.COSINE}
+
+
+def create_app(client: Milvus = None, store: MetaStore = None) -> Flask:
+    app = Flask(__name__)
+    state = {"client": client, "store": store or MetaStore(os.environ.get("VDB_META_PATH", ":memory:"))}
+    lock = threading.Lock()
+    compat_bug = os.environ.get("VDB_COMPAT_LOOKUP_BUG", "0") == "1"
+
+    def engine() -> Milvus:
+        with lock:
+            if state["client"] is None:
+                m = Milvus()
+                status = m.connect(host=_HOST, port=_PORT)
+                if not status.OK():
+                    print("Server connect fail.", status.message)
+                    sys.exit(1)                      # as app.py:181-182
+                state["client"] = m
+            return state["client"]
+
+    def store_() -> MetaStore:
+        return state["store"]
+
+    def create_vector_db(name, dimensions, metric="ip", dtype="f32", index_type="IVFLAT"):
+        if store_().has_db(name):
+            return -1, "Error: Vector database with name: " + name + " already exists"
+        status, exists = engine().has_table(name)
+        if exists:
+            return -1, "Error: table with name: " + name + " exists in milvus (but not in postgres)"
+        store_().create_db(name, dimensions, index_type, metric)
+        engine().create_table({"table_name": name, "dimension": dimensions, "index_file_size": _INDEX_FILE_SIZE,
+                               "metric_type": _METRICS[metric], "dtype": dtype})
+        engine().create_index(name, {"index_type": IndexType.IVFLAT, "nlist": 2048})
+        return 1, "Vector database with name: " + name + " created"
+
+    def lookup_engine(dbname, vectors, k):
+        status, results = engine().search_vectors(table_name=dbname, query_records=vectors, top_k=k, nprobe=10)
+        out = []
+        for res in results:
+            seen, hits = set(), []
+            for r in res:                               # one line per distinct id, best first
+                if r.id in seen:
+                    continue
+                seen.add(r.id)
+                hits.append({"distance": r.distance, "vectorhash": r.id})
+            out.append(hits)
+        return out
+
+    @app.route("/")
+    def hello():
+        return "Total rows: " + str(len(store_().list_dbs()) + 1)     # the reference counts from 1 (app.py:163)
+
+    @app.route("/checkintegrity")
+    def check_integrity():
+        all_good = True
+        print("Table name\tExists in postgres\tExists in Milvus")
+        for name, _, _, _ in store_().list_dbs():
+            status, in_engine = engine().has_table(name)
+            print(name + "\t\tTrue\t\t\t\t" + str(in_engine))
+            all_good = all_good and in_engine
+        return "All ok" if all_good else "DB integrety bad. Check server output for details"
+
+    @app.route("/createdb")
+    def create_new_db():
+        try:
+            name = request.args.get("dbname")
+            dimensions = int(request.args.get("dimensions"))
+            metric = (request.args.get("metric") or "ip").lower()
+            dtype = (request.args.get("dtype") or "f32").lower()
+            if metric not in _METRICS:
+                return "Error: unknown metric " + metric, 400
+            code, text = create_vector_db(name, dimensions, metric, dtype)
+            return text
+        except (MetaStoreError, TypeError, ValueError) as exc:
+            return "Error: " + str(exc), 400
+
+    @app.route("/deletedb")
+    def delete_db():
+        name = request.args.get("dbname")
+        all_ok = True
+        status = engine().delete_table(name)
+        if status.code != 0:
+            all_ok = False
+            print(status.message)
+        try:
+            if not store_().drop_db(name):
+                all_ok = False
+        except MetaStoreError as exc:
+            all_ok = False
+            print("Error while deleting table", exc)
+        return "Table deleted" if all_ok else "Problem with deleting table. See server log for details"
+
+    @app.route("/insert", methods=["PUT"])
+    def insert_vector():
+        name = request.args.get("dbname")
+        body = request.json
+        asset_id, vector = body["name"], body["vector"]
+        vector_hash = hash_vector(vector)
+        try:
+            is_new = store_().add_mapping(name, vector_hash, asset_id)
+        except (MetaStoreError, Exception) as exc:      # unknown database etc.
+            return "Error: " + str(exc), 400
+        if is_new:
+            engine().insert(name, records=[vector], ids=[vector_hash])
+        return "hej"                                     # app.py:349
+
+    @app.route("/lookupexact", methods=["PUT"])
+    def lookup_exact():
+        name = request.args.get("dbname")
+        vector = request.json["vector"]
+        try:
+            return json.dumps(store_().assets(name, hash_vector(vector)))
+        except Exception as exc:
+            return "Error: " + str(exc), 400
+
+    def one_lookup(name, vector, hits):
+        exact = store_().assets(name, hash_vector(vector))
+        results = [{"distance": 0, "asset_ids": exact}]
+        for hit in hits:
+            assets = store_().assets(name, hit["vectorhash"])
+            results.append({"distance": hit["distance"], "asset_ids": exact if compat_bug else assets})
+        return results
+
+    @app.route("/lookup", methods=["PUT"])
+    def lookup():
+        name = request.args.get("dbname")
+        body = request.json
+        try:
+            k = int(request.args.get("k") or 10)
+            if "vectors" in body:
+                vectors = body["vectors"]
+                hits = lookup_engine(name, vectors, k)
+                if len(hits) != len(vectors):
+                    return json.dumps([])
+                return json.dumps([one_lookup(name, v, h) for v, h in zip(vectors, hits)])
+            vector = body["vector"]
+            hits = lookup_engine(name, [vector], k)
+            return json.dumps(one_lookup(name, vector, hits[0] if hits else []))
+        except Exception as exc:
+            return "Error: " + str(exc), 400
+
+    return app
+
+
+if __name__ == "__main__":
+    create_app().run(port=5001)                          # app.py:443

@@ -1,0 +1,81 @@
+"""GPU tests of the reference-facing surfaces: the pymilvus-shaped client used the way
+/root/reference/app.py uses it, and the HTTP routes of server/app.py over libvdb.so (the first
+BASELINE configuration: U[0,1) vectors inserted one per PUT, single-query cosine top-10)."""
+import json
+
+import numpy as np
+import pytest
+
+import cases
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def test_client_shim_as_the_reference_calls_it(engine):
+    from milvus import IndexType, MetricType, Milvus
+    m = Milvus()
+    assert m.connect(host="127.0.0.1", port="19530").OK()                     # app.py:176-178
+    name = "shimtable"
+    m.delete_table(name)
+    status, ok = m.has_table(name)                                             # app.py:120
+    assert status.OK() and ok is False
+    assert m.create_table({"table_name": name, "dimension": 8, "index_file_size": 32,
+                           "metric_type": MetricType.IP}).OK()                 # app.py:137-143
+    assert m.create_index(name, {"index_type": IndexType.IVFLAT, "nlist": 2048}).OK()   # app.py:145-149
+    assert m.has_table(name)[1] is True
+    rows = cases.make_rows("uniform", 9, 50, 8).astype(np.float64)             # JSON floats are float64
+    ids = [O.hash_vector(r.tolist()) for r in rows]
+    for r, i in zip(rows, ids):
+        m.insert(name, records=[r.tolist()], ids=[i])                          # app.py:325, one row per call
+    assert m.get_table_row_count(name) == (m.get_table_row_count(name)[0], 50)
+    q = rows[7].tolist()
+    status, results = m.search_vectors(table_name=name, query_records=[q], top_k=10, nprobe=10)   # app.py:384-391
+    assert status.OK() and len(results) == 1
+    res = results[0]
+    stored = O.prepare_store(rows.astype(np.float32), O.IP)
+    (wi, ws), = O.search(stored, np.array(ids, dtype=np.int64), np.array([q], dtype=np.float32), 10, O.IP)
+    assert [r.id for r in res] == [int(x) for x in wi]
+    assert [np.float32(r.distance) for r in res] == list(ws)
+    assert "id=" in repr(res[0])                                               # app.py:400 prints each hit
+    # errors come back as statuses, never exceptions
+    assert m.create_table({"table_name": name, "dimension": 8}).code != 0
+    status, results = m.search_vectors(table_name="absent", query_records=[q], top_k=10, nprobe=10)
+    assert not status.OK() and results == []
+    st = m.delete_table(name)                                                  # app.py:242-245
+    assert st.code == 0
+    assert m.delete_table(name).code != 0 and m.delete_table(name).message
+
+
+def test_http_routes_over_the_engine(engine):
+    from server.app import create_app
+    from server.metastore import MetaStore
+    http = create_app(store=MetaStore()).test_client()
+    name, d, n = "httpdb", 384, 400
+    http.get("/deletedb?dbname=" + name)
+    assert "created" in http.get("/createdb?dbname=%s&dimensions=%d&metric=cosine" % (name, d)).get_data(as_text=True)
+    rng = np.random.default_rng(0)
+    vecs = [rng.random(d).tolist() for _ in range(n)]                # createVector.py:6-8, seeded
+    for i, v in enumerate(vecs):
+        assert http.put("/insert?dbname=" + name, json={"name": "v%d" % i, "vector": v}).get_data(as_text=True) == "hej"
+    http.put("/insert?dbname=" + name, json={"name": "alias", "vector": vecs[3]})     # second asset, same vector
+    assert engine.count(name) == n
+    ids = np.array([O.hash_vector(v) for v in vecs], dtype=np.int64)
+    stored = O.prepare_store(np.asarray(vecs, dtype=np.float32), O.COSINE)
+    queries = [vecs[3], np.random.default_rng(1).random(d).tolist()]
+    for q in queries:
+        out = json.loads(http.put("/lookup?dbname=" + name, json={"name": "q", "vector": q}).get_data())
+        (wi, ws), = O.search(stored, ids, np.array([q], dtype=np.float32), 10, O.COSINE)
+        assert out[0]["distance"] == 0
+        assert out[0]["asset_ids"] == (["v3", "alias"] if q is vecs[3] else [])
+        assert len(out) == 11
+        for hit, want_id, want_sc in zip(out[1:], wi, ws):
+            idx = int(np.nonzero(ids == want_id)[0][0])
+            assert hit["asset_ids"] == (["v3", "alias"] if idx == 3 else ["v%d" % idx])
+            assert np.float32(hit["distance"]) == want_sc
+    batch = json.loads(http.put("/lookup?dbname=%s&k=5" % name, json={"vectors": queries}).get_data())
+    assert len(batch) == 2 and all(len(b) == 6 for b in batch)
+    assert json.loads(http.put("/lookupexact?dbname=" + name, json={"vector": vecs[3]}).get_data()) == ["v3", "alias"]
+    assert http.get("/checkintegrity").get_data(as_text=True) == "All ok"
+    assert http.get("/deletedb?dbname=" + name).get_data(as_text=True) == "Table deleted"
+    assert not engine.has_table(name)

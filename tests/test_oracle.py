@@ -155,3 +155,21 @@ def test_sharded_topk_merge_equals_global(n, k, shards, seed):
             part_s.append(s)
         mi, ms = O.topk(np.concatenate(part_s), np.concatenate(part_i), k, metric)
         assert np.array_equal(mi, gi) and np.array_equal(ms, gs)
+
+
+def test_c_restatement_matches_numpy_oracle():
+    from oracle import oracle_c as OC
+    x = O.synth_rows(3, 10, 800, 130)
+    assert np.array_equal(x.view(np.uint32), OC.synth_rows(3, 10, 800, 130).view(np.uint32))
+    q = O.synth_rows(4, 0, 1, 130)[0]
+    ids = cases.make_ids("hash", 1, 800)
+    for m in (O.IP, O.L2, O.COSINE):
+        for dt in (O.F32, O.BF16, O.F16):
+            st = O.prepare_store(x, m, dt)
+            qp = O.prepare_query(q, m)
+            a, b = O.scores(st, qp, m), OC.scores(st, qp, m)
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+            ai, as_ = O.topk(a, ids, 17, m)
+            bi, bs = OC.topk(a, ids, 17, m)
+            assert np.array_equal(ai, bi) and np.array_equal(as_.view(np.uint32), bs.view(np.uint32))
+    assert np.array_equal(O.normalize_rows(x).view(np.uint32), OC.normalize_rows(x).view(np.uint32))
