@@ -90,6 +90,8 @@ def main() -> None:
     ap.add_argument("--metric", default="cosine", choices=sorted(METRICS))
     ap.add_argument("--dtype", default="f32", choices=sorted(DTYPES))
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="0 disables the CPU baseline")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for N > 1 (nccl = RCCL; gloo rehearses the path on fewer GPUs)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -99,12 +101,19 @@ def main() -> None:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU path exists)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % ndev          # ranks share a GPU only in the --backend gloo rehearsal
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            if world > ndev:
+                raise SystemExit("%d ranks but %d GPUs: RCCL needs one GPU per rank" % (world, ndev))
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
-    eng = Engine(device=local_rank)
+    eng = Engine(device=dev_index)
     dt, esz = DTYPES[args.dtype]
     metric = METRICS[args.metric]
     first, last = shard_range(args.rows, world, rank)

@@ -1,0 +1,76 @@
+"""GPU test of the whole row-sharded product path with two processes (both on cuda:0, gloo as
+the collective because two RCCL ranks cannot share a GPU): per-rank tables over shard_range,
+vdb_search_dev into the record, one all-gather, vdb_merge_records_dev; result against the oracle
+on the unsharded data."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, ret):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    import cases
+    from oracle import oracle as O
+    from vectordb_amd import _lib
+    from vectordb_amd.engine import Engine
+    from vectordb_amd.sharded import ShardedSearcher, gpu_backend, shard_range
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        eng = Engine(0)
+        n, d, k, nq = 20_000, 96, 10, 3
+        rows = cases.make_rows("synth", 7, n, d)
+        ids = cases.make_ids("hash", 7, n)
+        q = cases.make_queries("synth", 7, nq, d, rows)
+        lo, hi = shard_range(n, world, rank)
+        name = "shard_r%d" % rank
+        eng.create_table(name, d, _lib.METRIC_COSINE, _lib.F32)
+        eng.insert(name, rows[lo:hi], ids[lo:hi])
+        ls, mg = gpu_backend(eng, name, nq, k, _lib.METRIC_COSINE)
+        s = ShardedSearcher(nq, k, torch.device("cuda", 0), ls, mg)
+        out = s.search(torch.from_numpy(q).cuda())
+        torch.cuda.synchronize()
+        want = O.search(O.prepare_store(rows, O.COSINE), ids, q, k, O.COSINE)
+        ok = True
+        for qi, (wi, ws) in enumerate(want):
+            ok &= int(out.counts[qi]) == k
+            ok &= np.array_equal(out.ids[qi].cpu().numpy(), wi)
+            ok &= np.array_equal(out.scores[qi].cpu().numpy().view(np.uint32), ws.view(np.uint32))
+        ret[rank] = bool(ok)
+        eng.drop_table(name)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharded_search_on_one_gpu():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        ret = mgr.dict()
+        procs = [ctx.Process(target=_worker, args=(r, world, port, ret)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout=240)
+        for p in procs:
+            assert p.exitcode == 0, "rank exited with %s" % p.exitcode
+        assert dict(ret) == {0: True, 1: True}

@@ -77,7 +77,14 @@ class ShardedSearcher:
         self.local_search(queries, self.rec_views)
         if self.world == 1:
             return self.rec_views
-        dist.all_gather_into_tensor(self.gathered, self.rec, group=self.group)
+        if self.rec.is_cuda and dist.get_backend(self.group) == "gloo":
+            # rehearsal of the N > 1 path without RCCL (ranks sharing one GPU): gloo moves host
+            # memory, so the record is staged through the host around the same collective
+            host = torch.empty(self.gathered.numel(), dtype=torch.uint8)
+            dist.all_gather_into_tensor(host, self.rec.cpu(), group=self.group)
+            self.gathered.copy_(host)
+        else:
+            dist.all_gather_into_tensor(self.gathered, self.rec, group=self.group)
         self.merge(self.gathered, self.world, self.out_views)
         return self.out_views
 
