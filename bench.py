@@ -205,6 +205,16 @@ def main() -> None:
             },
             "sample_result": {"ids": [int(x) for x in last_ids[0][:3]], "scores": [float(x) for x in last_scores[0][:3]]},
         }
+        # HBM bytes per scan launch from the PMC pass (rocprofv3 --pmc FETCH_SIZE, a run of its own,
+        # gfx950 half-count correction applied); only known for configurations that were profiled
+        try:
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+                pmc = json.load(fh).get("scan_kernel|rows_per_gpu=%d|dim=%d|dtype=%s" % (n_local, args.dim, args.dtype))
+            if pmc and batched == 0:
+                line["roofline"]["traffic"] = pmc["hbm_read_bytes_per_launch"]
+                line["roofline"]["traffic_source"] = pmc["source"]
+        except (OSError, ValueError):
+            pass
         if batched > 0:
             # batched path: the dominant kernel is the fp32 MFMA GEMM over all rows (one launch per
             # 1024-query chunk); algorithmic flops = 2 * rows * dim * queries per launch

@@ -73,10 +73,11 @@ __device__ __forceinline__ double wave_tree_sum(double acc) {
 
 // Canonical fp64 score of one stored row against a prepared query, computed by one wave.
 // Every lane returns the same value.  Lane l owns elements l, l+64, ... in increasing order;
-// sixteen of them are fetched per round trip.  Elements past d are taken as zero, which leaves
-// the sum unchanged bit for bit (the accumulator is never -0.0).
-__device__ __forceinline__ double canon_score(const char* row, const float* q, int d, int dt,
-                                              bool l2, int lane) {
+// sixteen of them are fetched per round trip with unconditional loads (indices past d are
+// clamped and the value replaced by zero, which leaves the sum unchanged bit for bit: the
+// accumulator is never -0.0).
+template <int DT>
+__device__ __forceinline__ double canon_score_dt(const char* row, const float* q, int d, bool l2, int lane) {
 #pragma clang fp contract(off)
     double acc = 0.0;
     for (int j0 = lane; j0 < d; j0 += 64 * 16) {
@@ -84,9 +85,14 @@ __device__ __forceinline__ double canon_score(const char* row, const float* q, i
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
             const int j = j0 + 64 * u;
-            const bool ok = j < d;
-            xv[u] = ok ? load_elem(row, j, dt) : 0.f;
-            yv[u] = ok ? q[j] : 0.f;
+            const int jc = j < d ? j : d - 1;
+            float x;
+            if constexpr (DT == VDB_F32) x = ((const float*)row)[jc];
+            else if constexpr (DT == VDB_BF16) x = __uint_as_float((uint32_t)((const unsigned short*)row)[jc] << 16);
+            else x = f16_bits(((const unsigned short*)row)[jc]);
+            const float y = q[jc];
+            xv[u] = j < d ? x : 0.f;
+            yv[u] = j < d ? y : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
@@ -100,6 +106,13 @@ __device__ __forceinline__ double canon_score(const char* row, const float* q, i
         }
     }
     return wave_tree_sum(acc);
+}
+
+__device__ __forceinline__ double canon_score(const char* row, const float* q, int d, int dt,
+                                              bool l2, int lane) {
+    if (dt == VDB_F32) return canon_score_dt<VDB_F32>(row, q, d, l2, lane);
+    if (dt == VDB_BF16) return canon_score_dt<VDB_BF16>(row, q, d, l2, lane);
+    return canon_score_dt<VDB_F16>(row, q, d, l2, lane);
 }
 
 // Kernels that ask for more than the default 64 KiB of dynamic LDS must say so first.
@@ -483,14 +496,16 @@ __device__ __forceinline__ void hist_add_aggregated(int* hist, bool active, int 
 // 8 * blockDim.x values may sit in registers (slot u <-> value u * blockDim.x + tid).  On return:
 // ctl[4] = number of real values; if that is <= K the caller takes them all (returns true);
 // otherwise `thr` is the key of the K-th largest and `need` how many values equal to it belong
-// to the K (all values with a larger key do).  Called by every thread of the block.
+// to the K (all values with a larger key do).  With npass < 4 only the leading 8*npass bits are
+// resolved and `thr` is a lower bound of the K-th largest key (`need` is then meaningless).
+// Called by every thread of the block.
 template <typename F>
 __device__ __forceinline__ bool select_kth(F get, long long count, int K, int* hist, int* ctl,
-                                           uint32_t& thr, int& need) {
+                                           uint32_t& thr, int& need, int npass = 4) {
     const int nth = blockDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t prefix = 0;
     need = K;
-    for (int pass = 0; pass < 4; ++pass) {
+    for (int pass = 0; pass < npass; ++pass) {
         if (tid < 256) hist[tid] = 0;
         __syncthreads();
         const int shift = 24 - 8 * pass;
@@ -531,7 +546,9 @@ __device__ __forceinline__ bool select_kth(F get, long long count, int K, int* h
         prefix = (uint32_t)ctl[0];
         need = ctl[1];
     }
-    thr = prefix;
+    // with fewer than four passes the undecided low bits are zero: the lower edge of the bin
+    // that holds the K-th largest, i.e. a lower bound of it
+    thr = npass < 4 ? prefix << (32 - 8 * npass) : prefix;
     return false;
 }
 
@@ -575,6 +592,13 @@ finalize_kernel(FinParams p) {
     uint32_t thr = 0;
     int need = K;
     bool take_all;
+    // diagnostic build only (-DVDB_FIN_STAMPS): stage boundaries of query 0 in 10 ns ticks
+#ifdef VDB_FIN_STAMPS
+#define STAMP(n) do { if (tid == 0 && qi == 0) p.counters[8 + (n)] = (long long)wall_clock64(); } while (0)
+#else
+#define STAMP(n) do { } while (0)
+#endif
+    STAMP(0);
 
     // (A) lower bound from the list heads
     uint32_t lb = 0;
@@ -585,13 +609,14 @@ finalize_kernel(FinParams p) {
             float head[8];                       // read once, reused by the four passes
 #pragma unroll
             for (int u = 0; u < 8; ++u) { const long long b = (long long)u * nth + tid; head[u] = (b < p.G) ? gs[b * K] : neg_inf(); }
-            all = select_kth([&](long long, int u) { return head[u]; }, (long long)p.G, K, hist, ctl, lb, nd);
+            all = select_kth([&](long long, int u) { return head[u]; }, (long long)p.G, K, hist, ctl, lb, nd, 2);
         } else {
-            all = select_kth([&](long long b, int) { return gs[b * K]; }, (long long)p.G, K, hist, ctl, lb, nd);
+            all = select_kth([&](long long b, int) { return gs[b * K]; }, (long long)p.G, K, hist, ctl, lb, nd, 2);
         }
         if (all) lb = 0;
         __syncthreads();
     }
+    STAMP(1);
     // (B) survivors of the lower bound, appended wave by wave
     for (long long i0 = 0; !FLAT && i0 < M; i0 += (long long)nth * 32) {
         float v[32];                             // 32 loads in flight: one round trip per 32*nth candidates
@@ -612,6 +637,7 @@ finalize_kernel(FinParams p) {
         }
     }
     __syncthreads();
+    STAMP(2);
     const int S = ctl[5];
     if (!FLAT && S <= FIN_CAP) {
         // (C) exact K best among the survivors
@@ -638,6 +664,7 @@ finalize_kernel(FinParams p) {
         }
     }
     __syncthreads();
+    STAMP(3);
     const int nvalid = take_all ? ctl[4] : K;
     const uint32_t prefix = thr;
 
@@ -657,6 +684,7 @@ finalize_kernel(FinParams p) {
         if (lane == 0) { RS[i] = key; RT[i] = id; }
     }
     __syncthreads();
+    STAMP(4);
     if (wave == 0) {
         // ids may legitimately equal TAG_NONE; empties are told apart by position (>= nvalid)
         // because a real entry is never worse than an empty one with the same key and id.
@@ -710,6 +738,7 @@ finalize_kernel(FinParams p) {
                 }
             }
             if (!cert) { const int pos = atomicAdd(&p.need_exact[0], 1); p.need_exact[1 + pos] = qi; }
+            STAMP(5);
             atomicAdd((unsigned long long*)&p.counters[0], 1ull);
         }
     }

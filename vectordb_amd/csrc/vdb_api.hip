@@ -427,8 +427,8 @@ int vdb_init(int device) {
     e = hipGetDeviceProperties(&prop, device);
     if (e != hipSuccess) return fail(VDB_ENOGPU, std::string("hipGetDeviceProperties: ") + hipGetErrorString(e));
     G.n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    e = hipMalloc((void**)&G.d_counters, 2 * sizeof(long long));
-    if (e == hipSuccess) e = hipMemset(G.d_counters, 0, 2 * sizeof(long long));
+    e = hipMalloc((void**)&G.d_counters, 32 * sizeof(long long));
+    if (e == hipSuccess) e = hipMemset(G.d_counters, 0, 32 * sizeof(long long));
     if (e == hipSuccess) e = hipStreamCreate(&G.insert_stream);
     if (e != hipSuccess) return fail(VDB_ENOGPU, std::string("device set-up: ") + hipGetErrorString(e));
     G.device = device;
@@ -787,6 +787,14 @@ int vdb_bench_read_dev(const void* buf_dev, int64_t bytes, int nt, int blocks, i
     VDB_HIP(launch_read_bw(buf_dev, bytes, nt, blocks, threads, (unsigned int*)G.d_counters, (hipStream_t)stream));
     return VDB_OK;
 }
+
+#ifdef VDB_FIN_STAMPS
+// diagnostic build only: raw counter block (finalize stage stamps live at [8..])
+int vdb_debug_read(long long* out32) {
+    (void)hipDeviceSynchronize();
+    return hipMemcpy(out32, G.d_counters, 32 * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -5;
+}
+#endif
 
 int vdb_prof_enable(int on) {
     G.prof_on.store(on ? 1 : 0);
