@@ -36,6 +36,7 @@ __device__ __forceinline__ float load_elem(const char* row, int j, int dt) {
 }
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4s __attribute__((ext_vector_type(4)));
 
 // 16-byte row load; NT = non-temporal cache policy (rows are read once per scan)
 template <bool NT>
@@ -63,6 +64,29 @@ __device__ __forceinline__ float dot_unit(const u32x4& x, const float* q, float 
         acc = fmaf(f16_bits(x.w), q[6], acc); acc = fmaf(f16_bits(x.w >> 16), q[7], acc);
     }
     return acc;
+}
+
+// fp32 all-reduce over groups of LPR consecutive lanes without the LDS crossbar: DPP quad
+// permutes and row mirrors inside 16-lane rows, permlane swaps across rows.  Every lane of a
+// group ends with the group's sum (the pairing differs from an xor butterfly, which is
+// irrelevant for the fast score).
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+    if constexpr (LPR >= 2)  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    if constexpr (LPR >= 4)  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    if constexpr (LPR >= 8)  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    if constexpr (LPR >= 16) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+    if constexpr (LPR >= 32) {
+        const unsigned u = __builtin_bit_cast(unsigned, v);
+        const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+        v = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+    }
+    if constexpr (LPR >= 64) {
+        const unsigned u = __builtin_bit_cast(unsigned, v);
+        const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        v = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+    }
+    return v;
 }
 
 __device__ __forceinline__ double wave_tree_sum(double acc) {
@@ -174,8 +198,9 @@ struct ScanParams {
     int          K, C;
     int          l2;
     int          contiguous;
-    float*       cand_s;    // [nq][G][K]
+    float*       cand_s;    // [nq][G*W][K]: one sorted list per wave
     long long*   cand_t;
+    float*       cand_h;    // [nq][G*W]: best key of each list, contiguous for the finalize kernel
 };
 
 // Launch tunables of the scan (set through vdb_set_option, defaults chosen by measurement).
@@ -252,8 +277,7 @@ scan_kernel(ScanParams p) {
             float acc = 0.f;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) acc = dot_unit<DT>(x[u][c], qv[c], acc);
-#pragma unroll
-            for (int s = LPR >> 1; s >= 1; s >>= 1) acc += __shfl_xor(acc, s);
+            acc = group_sum<LPR>(acc);
             const long long r = base + u * RPI + grp;
             const float key = p.l2 ? (2.f * acc - nn[u]) : acc;
             const bool pass = (r <= last) && (lir == 0) && better(key, r, sel.thr_s, sel.thr_t);
@@ -261,10 +285,12 @@ scan_kernel(ScanParams p) {
         }
     }
 
-    block_merge(sel, S_all, T_all, W, wave, lane);
-    if (wave == 0) {
-        const size_t o = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * p.K;
-        for (int i = lane; i < p.K; i += 64) { p.cand_s[o + i] = S_all[i]; p.cand_t[o + i] = T_all[i]; }
+    // every wave hands over its own sorted list: no merge inside the block
+    sel.compact(lane);
+    {
+        const size_t o = (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * W + wave) * p.K;
+        for (int i = lane; i < p.K; i += 64) { p.cand_s[o + i] = sel.s[i]; p.cand_t[o + i] = sel.t[i]; }
+        if (lane == 0) p.cand_h[o / p.K] = sel.s[0];
     }
 }
 
@@ -323,8 +349,7 @@ scan_kernel_generic(ScanParams p) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             float a = acc[u];
-#pragma unroll
-            for (int s = 32; s >= 1; s >>= 1) a += __shfl_xor(a, s);
+            a = group_sum<64>(a);
             const long long r = base + u;
             const long long rc = r < last ? r : last;
             const float key = p.l2 ? (2.f * a - p.n2[rc]) : a;
@@ -333,10 +358,12 @@ scan_kernel_generic(ScanParams p) {
         }
     }
 
-    block_merge(sel, S_all, T_all, W, wave, lane);
-    if (wave == 0) {
-        const size_t o = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * p.K;
-        for (int i = lane; i < p.K; i += 64) { p.cand_s[o + i] = S_all[i]; p.cand_t[o + i] = T_all[i]; }
+    // every wave hands over its own sorted list: no merge inside the block
+    sel.compact(lane);
+    {
+        const size_t o = (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * W + wave) * p.K;
+        for (int i = lane; i < p.K; i += 64) { p.cand_s[o + i] = sel.s[i]; p.cand_t[o + i] = sel.t[i]; }
+        if (lane == 0) p.cand_h[o / p.K] = sel.s[0];
     }
 }
 
@@ -399,12 +426,13 @@ static hipError_t launch_scan_dt(const ScanShape& s, dim3 grid, dim3 block, size
 }
 
 hipError_t launch_scan(const TableView& t, const float* qprep, int64_t nq, int dpad,
-                       const SelGeom& g, int G, float* cand_s, long long* cand_t, hipStream_t st) {
+                       const SelGeom& g, int G, float* cand_s, long long* cand_t, float* cand_h,
+                       hipStream_t st) {
     ScanParams p;
     p.rows = t.rows; p.n2 = t.n2; p.q = qprep; p.n = t.n; p.m = t.m; p.dpad = dpad;
     p.K = g.K; p.C = g.C; p.l2 = (t.metric == VDB_METRIC_L2) ? 1 : 0;
     p.contiguous = g_tune.contiguous;
-    p.cand_s = cand_s; p.cand_t = cand_t;
+    p.cand_s = cand_s; p.cand_t = cand_t; p.cand_h = cand_h;
     const ScanShape s = scan_shape(t.m, t.dt);
     const dim3 grid((unsigned)G, (unsigned)nq), block((unsigned)g.W * 64);
     const size_t lds = (size_t)g.W * g.C * (sizeof(float) + sizeof(long long));
@@ -454,6 +482,7 @@ struct FinParams {
     int              K, C, G, k;
     const float*     cand_s;
     const long long* cand_t;
+    const float*     cand_h;     // lists mode: [nq][G] list heads
     long long*       out_ids;
     float*           out_scores;
     int*             out_counts;
@@ -553,6 +582,17 @@ __device__ __forceinline__ bool select_kth(F get, long long count, int K, int* h
 }
 
 constexpr int FIN_CAP = 2048;     // survivors of the pre-filter kept in LDS
+constexpr int FIN_RANK_MAX = 256;  // up to this many values are ranked directly (quadratic) instead of radix-selected
+
+// Position of value i among V[0..n) in descending order (ties by index).  Broadcast LDS reads.
+__device__ __forceinline__ int rank_of(const float* V, int n, int i, float vi) {
+    int rank = 0;
+    for (int j = 0; j < n; ++j) {
+        const float vj = V[j];
+        rank += (vj > vi || (vj == vi && j < i)) ? 1 : 0;
+    }
+    return rank;
+}
 
 // One block per query.  The G per-block candidate lists arrive sorted, so the K-th largest list
 // head is a lower bound of the K-th best key overall; everything below it is dropped with one
@@ -600,46 +640,94 @@ finalize_kernel(FinParams p) {
 #endif
     STAMP(0);
 
-    // (A) lower bound from the list heads
+    // (A) lower bound from the list heads; (B) walk only the lists whose head survives it
     uint32_t lb = 0;
-    if (!FLAT && p.G > K) {
-        int nd;
-        bool all;
-        if (p.G <= 8 * nth) {
-            float head[8];                       // read once, reused by the four passes
+    const bool heads_in_regs = !FLAT && p.G <= 8 * nth;
+    if (heads_in_regs) {
+        const float* gh = p.cand_h + (size_t)qi * p.G;
+        // thread t owns the lpt consecutive lists t*lpt ... (the waves of one scan block)
+        const int lpt = (p.G + nth - 1) / nth;               // <= 8
+        float head[8];
+        float tmax = neg_inf();
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const long long b = (long long)u * nth + tid; head[u] = (b < p.G) ? gs[b * K] : neg_inf(); }
-            all = select_kth([&](long long, int u) { return head[u]; }, (long long)p.G, K, hist, ctl, lb, nd, 2);
-        } else {
-            all = select_kth([&](long long b, int) { return gs[b * K]; }, (long long)p.G, K, hist, ctl, lb, nd, 2);
+        for (int u = 0; u < 8; ++u) {
+            const long long b = (long long)tid * lpt + u;
+            head[u] = (u < lpt && b < p.G) ? gh[b] : neg_inf();
+            tmax = fmaxf(tmax, head[u]);
         }
-        if (all) lb = 0;
-        __syncthreads();
-    }
-    STAMP(1);
-    // (B) survivors of the lower bound, appended wave by wave
-    for (long long i0 = 0; !FLAT && i0 < M; i0 += (long long)nth * 32) {
-        float v[32];                             // 32 loads in flight: one round trip per 32*nth candidates
+        if ((p.G + lpt - 1) / lpt > K) {
+            // every thread's best head is a distinct candidate: the K-th largest of those (lower
+            // edge of its 16-bit radix bin) is a lower bound of the K-th best key overall
+            int nd;
+            const bool all = select_kth([&](long long, int) { return tmax; }, (long long)((p.G + lpt - 1) / lpt), K, hist, ctl, lb, nd, 2);
+            if (all) lb = 0;
+            __syncthreads();
+        }
+        STAMP(1);
+        // the lists are sorted: a list contributes its leading entries down to the bound
 #pragma unroll
-        for (int u = 0; u < 32; ++u) { const long long i = i0 + (long long)u * nth + tid; v[u] = (i < M) ? gs[i] : neg_inf(); }
+        for (int u = 0; u < 8; ++u) {
+            const long long b = (long long)tid * lpt + u;
+            if (u < lpt && b < p.G && head[u] > neg_inf() && fkey(head[u]) >= lb) {
+                bool more = true;
+                for (int i = 0; more && i < K; i += 4) {
+                    const f32x4s v = *(const f32x4s*)(gs + b * K + i);
 #pragma unroll
-        for (int u = 0; u < 32; ++u) {
-            if (i0 + (long long)u * nth >= M) continue;              // block-uniform
-            const bool pass = (v[u] > neg_inf()) && fkey(v[u]) >= lb;
-            const unsigned long long m = __ballot(pass);
-            if (m) {
-                int base = 0;
-                if (lane == 0) base = atomicAdd(&ctl[5], __popcll(m));
-                base = __shfl(base, 0);
-                const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-                if (pass && pos < FIN_CAP) { VS[pos] = v[u]; VI[pos] = (int)(i0 + (long long)u * nth + tid); }
+                    for (int e = 0; e < 4; ++e) {
+                        const float x = v[e];
+                        if (more && x > neg_inf() && fkey(x) >= lb) {
+                            const int pos = atomicAdd(&ctl[5], 1);
+                            if (pos < FIN_CAP) { VS[pos] = x; VI[pos] = (int)(b * K + i + e); }
+                        } else {
+                            more = false;
+                        }
+                    }
+                }
+            }
+        }
+    } else if (!FLAT) {
+        if (p.G > K) {
+            int nd;
+            const bool all = select_kth([&](long long b, int) { return gs[b * K]; }, (long long)p.G, K, hist, ctl, lb, nd, 2);
+            if (all) lb = 0;
+            __syncthreads();
+        }
+        STAMP(1);
+        for (long long i0 = 0; i0 < M; i0 += (long long)nth * 32) {
+            float v[32];                             // 32 loads in flight: one round trip per 32*nth candidates
+#pragma unroll
+            for (int u = 0; u < 32; ++u) { const long long i = i0 + (long long)u * nth + tid; v[u] = (i < M) ? gs[i] : neg_inf(); }
+#pragma unroll
+            for (int u = 0; u < 32; ++u) {
+                if (i0 + (long long)u * nth >= M) continue;              // block-uniform
+                const bool pass = (v[u] > neg_inf()) && fkey(v[u]) >= lb;
+                const unsigned long long m = __ballot(pass);
+                if (m) {
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&ctl[5], __popcll(m));
+                    base = __shfl(base, 0);
+                    const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+                    if (pass && pos < FIN_CAP) { VS[pos] = v[u]; VI[pos] = (int)(i0 + (long long)u * nth + tid); }
+                }
             }
         }
     }
     __syncthreads();
     STAMP(2);
     const int S = ctl[5];
-    if (!FLAT && S <= FIN_CAP) {
+    if (!FLAT && S <= FIN_RANK_MAX) {
+        // (C) few survivors: rank them directly; the K best land in SS/ST already ordered
+        take_all = S <= K;
+        for (int j = tid; j < S; j += nth) {
+            const float sc = VS[j];
+            const int r = rank_of(VS, S, j, sc);
+            if (r < K) { SS[r] = sc; ST[r] = gt[VI[j]]; }
+            if (r == K - 1) ctl[7] = (int)fkey(sc);
+        }
+        __syncthreads();
+        thr = (uint32_t)ctl[7];
+        if (tid == 0) ctl[4] = S;
+    } else if (!FLAT && S <= FIN_CAP) {
         // (C) exact K best among the survivors
         take_all = select_kth([&](long long j, int) { return VS[j]; }, (long long)S, K, hist, ctl, thr, need);
         for (int j = tid; j < S; j += nth) {
@@ -746,13 +834,13 @@ finalize_kernel(FinParams p) {
 
 hipError_t launch_finalize(const TableView& t, const float* qprep, const QInfo* qinfo, int64_t nq,
                            int dpad, const SelGeom& g, int G, int k,
-                           const float* cand_s, const long long* cand_t,
+                           const float* cand_s, const long long* cand_t, const float* cand_h,
                            long long* out_ids, float* out_scores, int* out_counts,
                            int* need_exact, long long* counters, hipStream_t st) {
     FinParams p;
     p.t = t; p.q = qprep; p.qinfo = qinfo; p.dpad = dpad;
     p.K = g.K; p.C = g.C; p.G = G; p.k = k;
-    p.cand_s = cand_s; p.cand_t = cand_t;
+    p.cand_s = cand_s; p.cand_t = cand_t; p.cand_h = cand_h;
     p.out_ids = out_ids; p.out_scores = out_scores; p.out_counts = out_counts;
     p.need_exact = need_exact; p.counters = counters;
     p.flat_cnt = nullptr; p.flat_cap = 0; p.flat_tau = nullptr; p.flat_lost = nullptr;
@@ -773,7 +861,7 @@ hipError_t launch_finalize_flat(const TableView& t, const float* qprep, const QI
     FinParams p;
     p.t = t; p.q = qprep; p.qinfo = qinfo; p.dpad = dpad;
     p.K = g.K; p.C = g.C; p.G = 0; p.k = k;
-    p.cand_s = cand_s; p.cand_t = cand_t;
+    p.cand_s = cand_s; p.cand_t = cand_t; p.cand_h = nullptr;
     p.out_ids = out_ids; p.out_scores = out_scores; p.out_counts = out_counts;
     p.need_exact = need_exact; p.counters = counters;
     p.flat_cnt = cnt; p.flat_cap = cap; p.flat_tau = tau; p.flat_lost = lost;

@@ -43,6 +43,7 @@ struct Workspace {
     bool        used = false;
     DevBuf qprep, qinfo, cand_s, cand_t, need_exact;      // search scratch
     DevBuf small;                                         // batched path: cnt | lost | thr0 | thr1
+    DevBuf cand_h;                                        // scan path: list heads
     DevBuf q_raw, o_ids, o_scores, o_counts;              // staging of the host entry point
 };
 
@@ -215,8 +216,9 @@ static int search_scan_path(const TableView& tv, const SelGeom& g, int dpad, int
     int rc;
     if ((rc = ensure(ws.qprep, (size_t)nqc * dpad * sizeof(float), ws.last_stream))) return rc;
     if ((rc = ensure(ws.qinfo, (size_t)nqc * sizeof(QInfo), ws.last_stream))) return rc;
-    if ((rc = ensure(ws.cand_s, (size_t)nqc * Gx * g.K * sizeof(float), ws.last_stream))) return rc;
-    if ((rc = ensure(ws.cand_t, (size_t)nqc * Gx * g.K * sizeof(long long), ws.last_stream))) return rc;
+    if ((rc = ensure(ws.cand_s, (size_t)nqc * Gx * g.W * g.K * sizeof(float), ws.last_stream))) return rc;
+    if ((rc = ensure(ws.cand_t, (size_t)nqc * Gx * g.W * g.K * sizeof(long long), ws.last_stream))) return rc;
+    if ((rc = ensure(ws.cand_h, (size_t)nqc * Gx * g.W * sizeof(float), ws.last_stream))) return rc;
     if ((rc = ensure(ws.need_exact, (size_t)(nqc + 1) * sizeof(int), ws.last_stream))) return rc;
     for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
         const int64_t nqi = nq - q0 < chunk ? nq - q0 : chunk;
@@ -228,9 +230,9 @@ static int search_scan_path(const TableView& tv, const SelGeom& g, int dpad, int
         VDB_HIP(launch_prep_query(q_dev + (size_t)q0 * tv.d, nqi, tv.d, dpad, tv.metric, qprep, qinfo, ne, st));
         ProfScope prof;
         if ((rc = prof.begin(st))) return rc;
-        VDB_HIP(launch_scan(tv, qprep, nqi, dpad, g, Gx, cs, ct, st));
+        VDB_HIP(launch_scan(tv, qprep, nqi, dpad, g, Gx, cs, ct, (float*)ws.cand_h.p, st));
         if ((rc = prof.end(st))) return rc;
-        VDB_HIP(launch_finalize(tv, qprep, qinfo, nqi, dpad, g, Gx, k, cs, ct,
+        VDB_HIP(launch_finalize(tv, qprep, qinfo, nqi, dpad, g, Gx * g.W, k, cs, ct, (const float*)ws.cand_h.p,
                                 out_ids + (size_t)q0 * k, out_scores + (size_t)q0 * k, out_counts + q0,
                                 ne, G.d_counters, st));
         VDB_HIP(launch_exact(tv, qprep, nqi, dpad, g, Gx, k, cs, ct,
@@ -453,7 +455,7 @@ int vdb_shutdown(void) {
     std::lock_guard<std::mutex> lk(G.mu);
     for (auto& w : G.free_ws) {
         for (DevBuf* b : {&w->qprep, &w->qinfo, &w->cand_s, &w->cand_t, &w->need_exact, &w->q_raw,
-                          &w->o_ids, &w->o_scores, &w->o_counts, &w->small})
+                          &w->o_ids, &w->o_scores, &w->o_counts, &w->small, &w->cand_h})
             if (b->p) (void)hipFree(b->p);
         if (w->stream) (void)hipStreamDestroy(w->stream);
         if (w->done) (void)hipEventDestroy(w->done);

@@ -60,12 +60,13 @@ hipError_t launch_prep_query(const float* q_raw, int64_t nq, int d, int dpad, in
 // Returns the grid width G through *out_G (cand arrays must hold nq*G*K entries; use scan_grid()).
 int  scan_grid(const TableView& t, const SelGeom& g, int n_cu);
 hipError_t launch_scan(const TableView& t, const float* qprep, int64_t nq, int dpad,
-                       const SelGeom& g, int G, float* cand_s, long long* cand_t, hipStream_t st);
+                       const SelGeom& g, int G, float* cand_s, long long* cand_t, float* cand_h,
+                       hipStream_t st);
 
 // Merge candidates, re-score them canonically (fp64), order by (score, id), certify.
 hipError_t launch_finalize(const TableView& t, const float* qprep, const QInfo* qinfo, int64_t nq,
                            int dpad, const SelGeom& g, int G, int k,
-                           const float* cand_s, const long long* cand_t,
+                           const float* cand_s, const long long* cand_t, const float* cand_h,
                            long long* out_ids, float* out_scores, int* out_counts,
                            int* need_exact, long long* counters, hipStream_t st);
 
