@@ -221,11 +221,21 @@ def main() -> None:
             nq_launch = min(args.nq, 1024)
             flops = 2.0 * n_local * args.dim * nq_launch
             tf = flops / avg_scan_s / 1e12 if avg_scan_s > 0 else 0.0
-            line["roofline"] = {
-                "bound": "mfma", "kernel": "gemm_thresh_kernel", "achieved": tf, "peak": MFMA_F32_PEAK_TF,
-                "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF, "traffic": None,
-                "flops_per_launch": flops, "avg_launch_ms": avg_scan_s * 1e3, "launches_timed": scan_launches,
-            }
+            if args.dtype == "f32":
+                line["roofline"] = {
+                    "bound": "mfma", "kernel": "gemm_thresh_kernel", "achieved": tf, "peak": MFMA_F32_PEAK_TF,
+                    "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF, "traffic": None,
+                    "flops_per_launch": flops, "avg_launch_ms": avg_scan_s * 1e3, "launches_timed": scan_launches,
+                }
+            else:
+                # 16-bit rows: 16x the MFMA rate, so up to a few hundred queries per batch the GEMM
+                # is bound by streaming the rows once per 128-query tile (shared through L2)
+                line["roofline"] = {
+                    "bound": "hbm", "kernel": "gemm16_thresh_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_scan_s * 1e3,
+                    "launches_timed": scan_launches, "mfma_tflops": tf, "mfma_frac_of_2500": tf / 2500.0,
+                }
         if world == 1 and args.cpu_seconds > 0 and args.nq == 1:
             line["cpu_baseline"] = cpu_baseline(args.rows, args.dim, args.k, args.metric, args.cpu_seconds)
         print(json.dumps(line), flush=True)

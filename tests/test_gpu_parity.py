@@ -385,3 +385,42 @@ def test_batched_path_matches_scan_path(engine, table_name):
     finally:
         engine.set_option("gemm_path", 1)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("metric", ["ip", "cosine", "l2"])
+@pytest.mark.parametrize("d,nq", [(96, 33), (200, 150), (768, 24)])
+def test_batched_gemm_path_16bit_parity(engine, table_name, metric, dtype, d, nq):
+    """bf16 / fp16 tables: the batch runs on the 16-bit MFMA with the query split into hi + lo
+    parts (bf16) or rounded once (fp16); results must still be the oracle's bit for bit."""
+    n = 70_000
+    rows = cases.make_rows("synth", 300 + d, n, d)
+    ids = cases.make_ids("hash", 300 + d, n)
+    q = cases.make_queries("synth", 300 + d, nq, d, rows)
+    m = cases.METRICS[metric]
+    stored = _load(engine, table_name, rows, ids, m, cases.DTYPES[dtype])
+    before = engine.stats()
+    _check(engine, table_name, stored, ids, q, 10, m)
+    after = engine.stats()
+    assert after[2] - before[2] == nq, "the batch did not take the GEMM path"
+    if dtype == "f16":
+        engine.set_option("gemm_split_f16", 1)
+        try:
+            _check(engine, table_name, stored, ids, q, 10, m)
+        finally:
+            engine.set_option("gemm_split_f16", 0)
+
+
+def test_streaming_16bit_gemm_variant_parity(engine, table_name):
+    """The alternative 16-bit batched kernel (row fragments straight to registers) stays selectable
+    through the `gemm16_variant` option and must give the same exact results."""
+    n, d, nq = 70_000, 200, 40
+    rows = cases.make_rows("synth", 41, n, d)
+    ids = cases.make_ids("hash", 41, n)
+    q = cases.make_queries("synth", 41, nq, d, rows)
+    stored = _load(engine, table_name, rows, ids, O.L2, O.BF16)
+    engine.set_option("gemm16_variant", 1)
+    try:
+        _check(engine, table_name, stored, ids, q, 10, O.L2)
+    finally:
+        engine.set_option("gemm16_variant", 0)

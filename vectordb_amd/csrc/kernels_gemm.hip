@@ -133,6 +133,17 @@ gemm_thresh_kernel(GemmParams p) {
             }
         }
         // epilogue: C/D layout col = lane & 31 (query), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+        // squared norms of this lane's 32 rows, fetched as one batch of independent loads
+        float rn2[2][16];
+        if (p.l2) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long long row = row0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    rn2[mi][r] = p.n2[row < p.n ? row : p.n - 1];
+                }
+        }
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
             const int q = qt * GB_N + wn * 64 + ni * 32 + li;
@@ -142,7 +153,7 @@ gemm_thresh_kernel(GemmParams p) {
                 for (int r = 0; r < 16; ++r) {
                     const long long row = row0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     float key = acc[mi][ni][r];
-                    if (p.l2) key = 2.f * key - p.n2[row < p.n ? row : p.n - 1];
+                    if (p.l2) key = 2.f * key - rn2[mi][r];
                     if (key > thr[ni] && row < p.n) {
                         const int pos = atomicAdd(&p.cnt[q], 1);
                         if (pos < p.cap) { p.cand_s[(size_t)q * p.cap + pos] = key; p.cand_t[(size_t)q * p.cap + pos] = row; }
@@ -256,6 +267,398 @@ hipError_t launch_kth_threshold(const float* cand_s, long long stride, const int
                                 int cap, int K, const float* thr_in, float* thr_out, int nq, hipStream_t st) {
     hipLaunchKernelGGL(kth_threshold_kernel, dim3((unsigned)nq), dim3(256), 0, st,
                        cand_s, stride, cnt, count_all, cap, K, thr_in, thr_out);
+    return hipGetLastError();
+}
+
+}  // namespace vdb
+
+// ---------------------------------------------------------------------------------------------
+// 16-bit tables (bf16 / fp16 rows): the same thresholded GEMM on the 16-bit MFMA
+// (v_mfma_f32_32x32x16_{bf16,f16}: exact products, fp32 accumulate, 16x the fp32 MFMA rate).
+// The fp32 query is presented to the MFMA as hi + lo in the rows' 16-bit type (hi = round(q),
+// lo = round(q - hi)); with SPLIT the lo part is accumulated too (relative query error 2^-16 for
+// bf16, 2^-22 for fp16), without it only hi is used (fp16: 2^-11).  That error is part of the
+// bound the certificate uses, so the result stays exact either way.
+namespace vdb {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4g __attribute__((ext_vector_type(4)));
+
+constexpr int HB_M = 128, HB_N = 128, HB_K = 64, HB_LD = HB_K + 8;   // LDS row = 72 halfs = 144 bytes
+
+struct Gemm16Params {
+    const unsigned short* X;     // [n][ldx] 16-bit elements
+    const float* n2;
+    const unsigned short* Qhi;   // [nq][dpad]
+    const unsigned short* Qlo;   // [nq][dpad] (SPLIT only)
+    const float* thr;
+    long long    n;
+    int          nq;
+    int          dpad;           // elements per row (multiple of 8)
+    int          ldx;
+    int          l2;
+    long long    tile0, tile_stride, ntiles;
+    float*       cand_s;
+    long long*   cand_t;
+    int*         cnt;
+    int*         lost;
+    int          cap;
+};
+
+template <int DT>
+__device__ __forceinline__ f32x16 mfma16(const u32x4g& a, const u32x4g& b, const f32x16& c) {
+    if constexpr (DT == VDB_BF16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+template <int DT, bool SPLIT>
+__global__ void __launch_bounds__(256, 2)
+gemm16_thresh_kernel(Gemm16Params p) {
+    __shared__ __attribute__((aligned(16))) unsigned short As[HB_M * HB_LD];
+    __shared__ __attribute__((aligned(16))) unsigned short Bh[HB_N * HB_LD];
+    __shared__ __attribute__((aligned(16))) unsigned short Bl[SPLIT ? HB_N * HB_LD : 8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int qt = blockIdx.y;
+    const int nks = (p.dpad + HB_K - 1) / HB_K;
+    const int d8 = p.dpad >> 3;                    // 16-byte units per row
+
+    int srow[4], sc8[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int f = tid + 256 * i; srow[i] = f >> 3; sc8[i] = f & 7; }
+    const unsigned short* qh[4];
+    const unsigned short* ql[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int q = qt * HB_N + srow[i];
+        if (q > p.nq - 1) q = p.nq - 1;
+        qh[i] = p.Qhi + (size_t)q * p.dpad;
+        ql[i] = SPLIT ? p.Qlo + (size_t)q * p.dpad : nullptr;
+    }
+    float thr[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int q = qt * HB_N + wn * 64 + ni * 32 + li;
+        thr[ni] = (q < p.nq) ? p.thr[q] : __builtin_huge_valf();
+    }
+
+    for (long long t = blockIdx.x; t < p.ntiles; t += gridDim.x) {
+        const long long row0 = (p.tile0 + t * p.tile_stride) * HB_M;
+        const unsigned short* xptr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            long long r = row0 + srow[i];
+            if (r > p.n - 1) r = p.n - 1;
+            xptr[i] = p.X + (size_t)r * p.ldx;
+        }
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+        u32x4g ra[4], rh[4], rl[4];
+        auto fetch = [&](int ks) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c8 = ks * (HB_K / 8) + sc8[i];
+                const bool ok = c8 < d8;
+                const int c = ok ? c8 * 8 : 0;
+                ra[i] = __builtin_nontemporal_load((const u32x4g*)(xptr[i] + c));     // rows stream once
+                rh[i] = *(const u32x4g*)(qh[i] + c);
+                if (SPLIT) rl[i] = *(const u32x4g*)(ql[i] + c);
+                if (!ok) { ra[i] = (u32x4g){0, 0, 0, 0}; rh[i] = (u32x4g){0, 0, 0, 0}; if (SPLIT) rl[i] = (u32x4g){0, 0, 0, 0}; }
+            }
+        };
+        fetch(0);
+        for (int ks = 0; ks < nks; ++ks) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                *(u32x4g*)&As[srow[i] * HB_LD + sc8[i] * 8] = ra[i];
+                *(u32x4g*)&Bh[srow[i] * HB_LD + sc8[i] * 8] = rh[i];
+                if (SPLIT) *(u32x4g*)&Bl[srow[i] * HB_LD + sc8[i] * 8] = rl[i];
+            }
+            __syncthreads();
+            if (ks + 1 < nks) fetch(ks + 1);
+#pragma unroll
+            for (int kk = 0; kk < HB_K / 16; ++kk) {
+                u32x4g a8[2], h8[2], l8[2];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) a8[mi] = *(const u32x4g*)&As[(wm * 64 + mi * 32 + li) * HB_LD + kk * 16 + lh * 8];
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    h8[ni] = *(const u32x4g*)&Bh[(wn * 64 + ni * 32 + li) * HB_LD + kk * 16 + lh * 8];
+                    if (SPLIT) l8[ni] = *(const u32x4g*)&Bl[(wn * 64 + ni * 32 + li) * HB_LD + kk * 16 + lh * 8];
+                }
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+                        acc[mi][ni] = mfma16<DT>(a8[mi], h8[ni], acc[mi][ni]);
+                        if (SPLIT) acc[mi][ni] = mfma16<DT>(a8[mi], l8[ni], acc[mi][ni]);
+                    }
+            }
+        }
+        float rn2[2][16];
+        if (p.l2) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long long row = row0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    rn2[mi][r] = p.n2[row < p.n ? row : p.n - 1];
+                }
+        }
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int q = qt * HB_N + wn * 64 + ni * 32 + li;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long long row = row0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    float key = acc[mi][ni][r];
+                    if (p.l2) key = 2.f * key - rn2[mi][r];
+                    if (key > thr[ni] && row < p.n) {
+                        const int pos = atomicAdd(&p.cnt[q], 1);
+                        if (pos < p.cap) { p.cand_s[(size_t)q * p.cap + pos] = key; p.cand_t[(size_t)q * p.cap + pos] = row; }
+                        else p.lost[q] = 1;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Streaming variant used for 16-bit tables.  With 16x the MFMA rate the GEMM is bound by reading
+// the rows, so the row operand gets the treatment of the single-query scan: every wave owns 32
+// rows x all 128 queries of the tile and loads its A fragments straight from global memory into
+// registers (16 bytes per lane, a ring of three k-steps in flight, no LDS round trip and no
+// barrier on the row stream); only the query tile, shared by the four waves and served by L2,
+// is staged through LDS.
+template <int DT, bool SPLIT>
+__global__ void __launch_bounds__(256, 2)
+gemm16_stream_kernel(Gemm16Params p) {
+    // the query chunk is double-buffered: chunk ks+1 is written while chunk ks is being read, so one
+    // barrier per k-step suffices and no wave waits for an LDS write it is about to read
+    __shared__ __attribute__((aligned(16))) unsigned short Bh[2][HB_N * HB_LD];
+    __shared__ __attribute__((aligned(16))) unsigned short Bl[2][SPLIT ? HB_N * HB_LD : 8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int qt = blockIdx.y;
+    const int nks = (p.dpad + HB_K - 1) / HB_K;
+    const int d8 = p.dpad >> 3;
+
+    int srow[4], sc8[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int f = tid + 256 * i; srow[i] = f >> 3; sc8[i] = f & 7; }
+    const unsigned short* qh[4];
+    const unsigned short* ql[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int q = qt * HB_N + srow[i];
+        if (q > p.nq - 1) q = p.nq - 1;
+        qh[i] = p.Qhi + (size_t)q * p.dpad;
+        ql[i] = SPLIT ? p.Qlo + (size_t)q * p.dpad : nullptr;
+    }
+    float thr[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const int q = qt * HB_N + ni * 32 + li;
+        thr[ni] = (q < p.nq) ? p.thr[q] : __builtin_huge_valf();
+    }
+
+    for (long long t = blockIdx.x; t < p.ntiles; t += gridDim.x) {
+        const long long row0 = (p.tile0 + t * p.tile_stride) * HB_M + wave * 32;
+        long long myrow = row0 + li;
+        if (myrow > p.n - 1) myrow = p.n - 1;
+        const unsigned short* xrow = p.X + (size_t)myrow * p.ldx;
+        f32x16 acc[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
+
+        // A fragments of one 64-element k-step: lane (li, lh) holds elements [16*kk + 8*lh, +8) of row li
+        u32x4g abuf[3][4];
+        auto fetch_a = [&](u32x4g (&dst)[4], int ks) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int c8 = ks * 8 + kk * 2 + lh;
+                const bool ok = ks < nks && c8 < d8;
+                // plain (cached) loads: four successive loads share each 128-byte line
+                dst[kk] = *(const u32x4g*)(xrow + (ok ? c8 * 8 : 0));
+                if (!ok) dst[kk] = (u32x4g){0, 0, 0, 0};
+            }
+        };
+        u32x4g rh[4], rl[4];
+        auto fetch_b = [&](int ks) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c8 = ks * 8 + sc8[i];
+                const bool ok = c8 < d8;
+                const int c = ok ? c8 * 8 : 0;
+                rh[i] = *(const u32x4g*)(qh[i] + c);
+                if (SPLIT) rl[i] = *(const u32x4g*)(ql[i] + c);
+                if (!ok) { rh[i] = (u32x4g){0, 0, 0, 0}; if (SPLIT) rl[i] = (u32x4g){0, 0, 0, 0}; }
+            }
+        };
+        auto store_b = [&](int buf) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                *(u32x4g*)&Bh[buf][srow[i] * HB_LD + sc8[i] * 8] = rh[i];
+                if (SPLIT) *(u32x4g*)&Bl[buf][srow[i] * HB_LD + sc8[i] * 8] = rl[i];
+            }
+        };
+        auto step = [&](const u32x4g (&a)[4], int ks) {
+            const int buf = ks & 1;
+            __syncthreads();          // chunk ks is complete in Bh[buf]; every wave has left chunk ks-1 (buffer buf^1)
+            if (ks + 1 < nks) store_b(buf ^ 1);            // registers hold chunk ks+1 (fetched one step ago)
+            if (ks + 2 < nks) fetch_b(ks + 2);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    const u32x4g h8 = *(const u32x4g*)&Bh[buf][(ni * 32 + li) * HB_LD + kk * 16 + lh * 8];
+                    acc[ni] = mfma16<DT>(a[kk], h8, acc[ni]);
+                    if (SPLIT) {
+                        const u32x4g l8 = *(const u32x4g*)&Bl[buf][(ni * 32 + li) * HB_LD + kk * 16 + lh * 8];
+                        acc[ni] = mfma16<DT>(a[kk], l8, acc[ni]);
+                    }
+                }
+            }
+        };
+        fetch_a(abuf[0], 0);
+        fetch_a(abuf[1], 1);
+        fetch_b(0);
+        __syncthreads();              // the previous row tile's last chunk has been read by every wave
+        store_b(0);
+        if (nks > 1) fetch_b(1);
+        for (int ks = 0; ks < nks; ks += 3) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                if (ks + j < nks) {                        // block-uniform
+                    fetch_a(abuf[(j + 2) % 3], ks + j + 2);
+                    step(abuf[j], ks + j);
+                }
+            }
+        }
+        float rn2[16];
+        if (p.l2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                rn2[r] = p.n2[row < p.n ? row : p.n - 1];
+            }
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int q = qt * HB_N + ni * 32 + li;
+            float key[16];
+            float best = -__builtin_huge_valf();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                key[r] = p.l2 ? 2.f * acc[ni][r] - rn2[r] : acc[ni][r];
+                best = fmaxf(best, key[r]);
+            }
+            if (__any(best > thr[ni])) {                   // almost never: one test per 32 x 32 tile
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long long row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (key[r] > thr[ni] && row < p.n) {
+                        const int pos = atomicAdd(&p.cnt[q], 1);
+                        if (pos < p.cap) { p.cand_s[(size_t)q * p.cap + pos] = key[r]; p.cand_t[(size_t)q * p.cap + pos] = row; }
+                        else p.lost[q] = 1;
+                    }
+                }
+            }
+        }
+    }
+}
+
+static int g_gemm16_variant = 0;       // 0 = LDS-staged tile kernel (default: faster up to ~256 queries), 1 = streaming kernel
+void set_gemm16_variant(int v) { g_gemm16_variant = v; }
+
+hipError_t launch_gemm16_thresh(const TableView& t, const unsigned short* qhi, const unsigned short* qlo,
+                                int split, int nq, int dpad, const float* thr,
+                                long long tile0, long long tile_stride, long long ntiles,
+                                float* cand_s, long long* cand_t, int* cnt, int* lost, int cap,
+                                int n_cu, hipStream_t st) {
+    if (ntiles <= 0) return hipSuccess;
+    Gemm16Params p;
+    p.X = (const unsigned short*)t.rows; p.n2 = t.n2; p.Qhi = qhi; p.Qlo = qlo; p.thr = thr; p.n = t.n; p.nq = nq;
+    p.dpad = dpad; p.ldx = t.m * 8; p.l2 = t.metric == VDB_METRIC_L2 ? 1 : 0;
+    p.tile0 = tile0; p.tile_stride = tile_stride; p.ntiles = ntiles;
+    p.cand_s = cand_s; p.cand_t = cand_t; p.cnt = cnt; p.lost = lost; p.cap = cap;
+    const int qtiles = (nq + HB_N - 1) / HB_N;
+    long long gx = (2LL * n_cu) / qtiles;
+    gx = gx / 8 * 8;
+    if (gx < 8) gx = 8;
+    if (gx > ntiles) gx = ntiles;
+    const dim3 grid((unsigned)gx, (unsigned)qtiles), block(256);
+    if (g_gemm16_variant == 1) {
+        if (t.dt == VDB_BF16) {
+            if (split) hipLaunchKernelGGL((gemm16_stream_kernel<VDB_BF16, true>), grid, block, 0, st, p);
+            else hipLaunchKernelGGL((gemm16_stream_kernel<VDB_BF16, false>), grid, block, 0, st, p);
+        } else {
+            if (split) hipLaunchKernelGGL((gemm16_stream_kernel<VDB_F16, true>), grid, block, 0, st, p);
+            else hipLaunchKernelGGL((gemm16_stream_kernel<VDB_F16, false>), grid, block, 0, st, p);
+        }
+        return hipGetLastError();
+    }
+    if (t.dt == VDB_BF16) {
+        if (split) hipLaunchKernelGGL((gemm16_thresh_kernel<VDB_BF16, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((gemm16_thresh_kernel<VDB_BF16, false>), grid, block, 0, st, p);
+    } else {
+        if (split) hipLaunchKernelGGL((gemm16_thresh_kernel<VDB_F16, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((gemm16_thresh_kernel<VDB_F16, false>), grid, block, 0, st, p);
+    }
+    return hipGetLastError();
+}
+
+// fp32 prepared queries -> hi/lo parts in the table's 16-bit type; a query whose hi part is not
+// finite (fp16 overflow) is flagged as lost so that the exact pass answers it.
+template <int DT>
+__global__ void __launch_bounds__(256)
+split_query16_kernel(const float* __restrict__ q, int dpad, unsigned short* __restrict__ hi,
+                     unsigned short* __restrict__ lo, int* __restrict__ lost) {
+    const size_t base = (size_t)blockIdx.x * dpad;
+    bool bad = false;
+    for (int j = threadIdx.x; j < dpad; j += blockDim.x) {
+        const float x = q[base + j];
+        unsigned short h, l;
+        float hf;
+        if constexpr (DT == VDB_BF16) {
+            const uint32_t u = __float_as_uint(x);
+            h = (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+            hf = __uint_as_float((uint32_t)h << 16);
+            const uint32_t v = __float_as_uint(x - hf);
+            l = (unsigned short)((v + 0x7fffu + ((v >> 16) & 1u)) >> 16);
+        } else {
+            const _Float16 hh = (_Float16)x;
+            hf = (float)hh;
+            const _Float16 ll = (_Float16)(x - hf);
+            __builtin_memcpy(&h, &hh, 2);
+            __builtin_memcpy(&l, &ll, 2);
+        }
+        if (!(fabsf(hf) <= 3.0e38f)) bad = true;
+        hi[base + j] = h;
+        lo[base + j] = l;
+    }
+    if (bad) lost[blockIdx.x] = 1;
+}
+
+hipError_t launch_split_query16(int dt, const float* qprep, int nq, int dpad, unsigned short* hi,
+                                unsigned short* lo, int* lost, hipStream_t st) {
+    if (dt == VDB_BF16) hipLaunchKernelGGL((split_query16_kernel<VDB_BF16>), dim3((unsigned)nq), dim3(256), 0, st, qprep, dpad, hi, lo, lost);
+    else hipLaunchKernelGGL((split_query16_kernel<VDB_F16>), dim3((unsigned)nq), dim3(256), 0, st, qprep, dpad, hi, lo, lost);
     return hipGetLastError();
 }
 

@@ -493,6 +493,8 @@ struct FinParams {
     int              flat_cap;
     const float*     flat_tau;   // [nq] every row that is not a candidate has a fast key <= tau
     const int*       flat_lost;  // [nq]
+    const int*       flat_bad;   // [nq] query not representable on the batched path (may be null)
+    double           dd_mult, extra_rel, extra_abs;   // see FlatBound
 };
 
 __device__ __forceinline__ int pow2_ceil_dev(int v) { int p = 1; while (p < v) p <<= 1; return p; }
@@ -804,7 +806,8 @@ finalize_kernel(FinParams p) {
             p.out_counts[qi] = cnt;
             // lists mode with fewer candidates than K: every stored row is among them
             bool cert = !FLAT && nvalid < K;
-            const bool usable = !FLAT || (p.flat_lost[qi] == 0 && (long long)cnt == (p.t.n < p.k ? p.t.n : (long long)p.k));
+            const bool usable = !FLAT || (p.flat_lost[qi] == 0 && (p.flat_bad == nullptr || p.flat_bad[qi] == 0) &&
+                                         (long long)cnt == (p.t.n < p.k ? p.t.n : (long long)p.k));
             if (!cert && cnt > 0 && usable) {
                 // theta: no row outside the candidate set has a larger fast key
                 double theta = (double)fkey_inv(prefix);
@@ -813,12 +816,13 @@ finalize_kernel(FinParams p) {
                 const double bx = sqrt((double)(*p.t.max_n2)) * (1.0 + 1e-6);
                 const double bq = (double)p.qinfo[qi].bq;
                 const double u = 5.9604644775390625e-08;   // 2^-24
-                const double dd = (double)(p.t.d + 16);
+                const double dd = (double)p.t.d * p.dd_mult + 16.0;
+                const double xq = p.extra_rel * bx * bq + p.extra_abs * bx;     // query rounding of the batched path
                 if (!l2) {
-                    const double eps = 1.05 * dd * u * bx * bq + 4.0 * u * fabs(theta) + 1e-37;
+                    const double eps = 1.05 * dd * u * bx * bq + xq + 4.0 * u * fabs(theta) + 1e-37;
                     cert = (double)RS[cnt - 1] > theta + eps;
                 } else {
-                    const double eps = 1.05 * u * (2.0 * dd * bx * bq + 4.0 * (bx * bx + 2.0 * bx * bq))
+                    const double eps = 1.05 * u * (2.0 * dd * bx * bq + 4.0 * (bx * bx + 2.0 * bx * bq)) + 2.0 * xq
                                        + 4.0 * u * fabs(theta) + 1e-37;
                     const double dist_k = -(double)RS[cnt - 1];
                     const double bound = p.qinfo[qi].n2 - theta - eps;     // outside rows are farther than this
@@ -843,7 +847,8 @@ hipError_t launch_finalize(const TableView& t, const float* qprep, const QInfo* 
     p.cand_s = cand_s; p.cand_t = cand_t; p.cand_h = cand_h;
     p.out_ids = out_ids; p.out_scores = out_scores; p.out_counts = out_counts;
     p.need_exact = need_exact; p.counters = counters;
-    p.flat_cnt = nullptr; p.flat_cap = 0; p.flat_tau = nullptr; p.flat_lost = nullptr;
+    p.flat_cnt = nullptr; p.flat_cap = 0; p.flat_tau = nullptr; p.flat_lost = nullptr; p.flat_bad = nullptr;
+    p.dd_mult = 1.0; p.extra_rel = 0.0; p.extra_abs = 0.0;
     int kr = 1; while (kr < g.K) kr <<= 1;
     const size_t lds = 1088 + (size_t)g.K * 12 + (size_t)kr * 12 + (size_t)FIN_CAP * 8;
     hipError_t e = allow_lds(finalize_kernel<false>, lds);
@@ -855,7 +860,7 @@ hipError_t launch_finalize(const TableView& t, const float* qprep, const QInfo* 
 hipError_t launch_finalize_flat(const TableView& t, const float* qprep, const QInfo* qinfo, int64_t nq,
                                 int dpad, const SelGeom& g, int k,
                                 const float* cand_s, const long long* cand_t, const int* cnt, int cap,
-                                const float* tau, const int* lost,
+                                const float* tau, const int* lost, const int* bad, const FlatBound& fb,
                                 long long* out_ids, float* out_scores, int* out_counts,
                                 int* need_exact, long long* counters, hipStream_t st) {
     FinParams p;
@@ -864,7 +869,8 @@ hipError_t launch_finalize_flat(const TableView& t, const float* qprep, const QI
     p.cand_s = cand_s; p.cand_t = cand_t; p.cand_h = nullptr;
     p.out_ids = out_ids; p.out_scores = out_scores; p.out_counts = out_counts;
     p.need_exact = need_exact; p.counters = counters;
-    p.flat_cnt = cnt; p.flat_cap = cap; p.flat_tau = tau; p.flat_lost = lost;
+    p.flat_cnt = cnt; p.flat_cap = cap; p.flat_tau = tau; p.flat_lost = lost; p.flat_bad = bad;
+    p.dd_mult = fb.dd_mult; p.extra_rel = fb.extra_rel; p.extra_abs = fb.extra_abs;
     int kr = 1; while (kr < g.K) kr <<= 1;
     const size_t lds = 1088 + (size_t)g.K * 12 + (size_t)kr * 12 + (size_t)FIN_CAP * 8;
     hipError_t e = allow_lds(finalize_kernel<true>, lds);

@@ -44,6 +44,7 @@ struct Workspace {
     DevBuf qprep, qinfo, cand_s, cand_t, need_exact;      // search scratch
     DevBuf small;                                         // batched path: cnt | lost | thr0 | thr1
     DevBuf cand_h;                                        // scan path: list heads
+    DevBuf q16;                                           // batched path, 16-bit tables: query hi | lo parts
     DevBuf q_raw, o_ids, o_scores, o_counts;              // staging of the host entry point
 };
 
@@ -77,7 +78,7 @@ struct Global {
     double cache_capacity_gb = 0.0;
     double insert_buffer_gb = 1.0;
     size_t table_bytes = 0;
-    int tune_nt = 1, tune_waves = 8, tune_bpc = 4, tune_contig = 1, tune_gemm = 1;
+    int tune_nt = 1, tune_waves = 8, tune_bpc = 4, tune_contig = 1, tune_gemm = 1, tune_split_f16 = 0;
     // host-insert staging (guarded by insert_mu)
     std::mutex insert_mu;
     DevBuf stage_rows, stage_ids;
@@ -242,39 +243,56 @@ static int search_scan_path(const TableView& tv, const SelGeom& g, int dpad, int
     return VDB_OK;
 }
 
-// Batched path (fp32 tables): MFMA GEMM with a thresholded epilogue, thresholds bootstrapped by
-// two smaller passes (exact top-K of the first rows, then a strided sample of the row tiles).
+// Batched path: MFMA GEMM with a thresholded epilogue (fp32 MFMA for fp32 tables, 16-bit MFMA
+// with the query split into hi + lo parts for bf16 / fp16 tables), thresholds bootstrapped by two
+// smaller passes (all scores of the first rows, then a strided sample of the row tiles).
 static int search_gemm_path(const TableView& tv, const SelGeom& g, int dpad, int64_t nq, const float* q_dev,
                             int k, long long* out_ids, float* out_scores, int* out_counts,
                             hipStream_t st, Workspace& ws) {
     const int K = g.K;
     const long long ntiles = (tv.n + 127) / 128;
-    long long tiles1 = (long long)std::ceil((double)tv.n * K / GEMM_TARGET / 128.0);
-    if (tiles1 < 8) tiles1 = 8;
-    if (tiles1 > ntiles) tiles1 = ntiles;
-    long long stride1 = ntiles / tiles1;
-    if (stride1 < 1) stride1 = 1;
-    tiles1 = ntiles / stride1;
-    long long n0 = (long long)((double)tiles1 * 128.0 * K / GEMM_TARGET);
-    if (n0 < 1024) n0 = 1024;
-    if (n0 > 8192) n0 = 8192;
-    if (n0 > tv.n) n0 = tv.n;
+    // Sample sizes of the threshold passes, in row tiles, smallest first.  Each pass is about
+    // GEMM_TARGET / K times larger than the one before, so that the K-th best key of one pass,
+    // used as the threshold of the next, lets about GEMM_TARGET candidates per query through.
+    // The first pass keeps every score of the first n0 <= GEMM_CAP rows.
+    const double ratio = GEMM_TARGET / (double)K;
+    long long n0 = tv.n < GEMM_CAP ? tv.n : GEMM_CAP;
+    std::vector<long long> level_tiles;              // intermediate passes (strided samples), then all tiles
+    {
+        std::vector<long long> rev;
+        long long tcur = ntiles;
+        while (true) {
+            long long tprev = (long long)std::ceil((double)tcur / ratio);
+            if (tprev < 8) tprev = 8;
+            if (tprev * 128 <= n0 || tprev >= tcur) break;
+            rev.push_back(tprev);
+            tcur = tprev;
+        }
+        for (size_t i = rev.size(); i > 0; --i) level_tiles.push_back(rev[i - 1]);
+    }
     TableView tv0 = tv;
     tv0.n = n0;
-    const int G0 = scan_grid(tv0, g, G.n_cu);
     const int Gx = scan_grid(tv, g, G.n_cu);
     const int64_t chunk = 1024;
     const int64_t nqc = nq < chunk ? nq : chunk;
     size_t slots = (size_t)nqc * GEMM_CAP;
-    if ((size_t)nqc * G0 * K > slots) slots = (size_t)nqc * G0 * K;
     if ((size_t)nqc * Gx * K > slots) slots = (size_t)nqc * Gx * K;
+    const bool half = tv.dt != VDB_F32;
+    // bf16 carries 8 significant bits: always use both parts; fp16 carries 11: the hi part alone
+    // leaves a relative query error of 2^-11, which the certificate accounts for
+    const int split = tv.dt == VDB_BF16 ? 1 : (G.tune_split_f16 ? 1 : 0);
+    FlatBound fb;
+    fb.dd_mult = (half && split) ? 2.0 : 1.0;
+    fb.extra_rel = !half ? 0.0 : (tv.dt == VDB_BF16 ? 1.6e-5 : (split ? 2.5e-7 : 4.9e-4));
+    fb.extra_abs = tv.dt == VDB_F16 ? 3.0e-8 * std::sqrt((double)tv.d) : 0.0;      // fp16 subnormal steps
     int rc;
     if ((rc = ensure(ws.qprep, (size_t)nqc * dpad * sizeof(float), ws.last_stream))) return rc;
     if ((rc = ensure(ws.qinfo, (size_t)nqc * sizeof(QInfo), ws.last_stream))) return rc;
     if ((rc = ensure(ws.cand_s, slots * sizeof(float), ws.last_stream))) return rc;
     if ((rc = ensure(ws.cand_t, slots * sizeof(long long), ws.last_stream))) return rc;
     if ((rc = ensure(ws.need_exact, (size_t)(nqc + 1) * sizeof(int), ws.last_stream))) return rc;
-    if ((rc = ensure(ws.small, (size_t)nqc * 16, ws.last_stream))) return rc;
+    if ((rc = ensure(ws.small, (size_t)nqc * 20, ws.last_stream))) return rc;
+    if (half && (rc = ensure(ws.q16, (size_t)nqc * dpad * 4, ws.last_stream))) return rc;
     for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
         const int nqi = (int)(nq - q0 < chunk ? nq - q0 : chunk);
         float* qprep = (float*)ws.qprep.p;
@@ -286,27 +304,38 @@ static int search_gemm_path(const TableView& tv, const SelGeom& g, int dpad, int
         int* lost = cnt + nqc;
         float* thr0 = (float*)(lost + nqc);
         float* thr1 = thr0 + nqc;
+        int* bad = (int*)(thr1 + nqc);
+        unsigned short* qhi = (unsigned short*)ws.q16.p;
+        unsigned short* qlo = half ? qhi + (size_t)nqc * dpad : nullptr;
+        auto gemm = [&](const TableView& v, const float* thr, long long stride, long long tiles) -> hipError_t {
+            if (half) return launch_gemm16_thresh(v, qhi, qlo, split, nqi, dpad, thr, 0, stride, tiles, cs, ct, cnt, lost, GEMM_CAP, G.n_cu, st);
+            return launch_gemm_thresh(v, qprep, nqi, dpad, thr, 0, stride, tiles, cs, ct, cnt, lost, GEMM_CAP, G.n_cu, st);
+        };
         VDB_HIP(launch_prep_query(q_dev + (size_t)q0 * tv.d, nqi, tv.d, dpad, tv.metric, qprep, qinfo, ne, st));
+        VDB_HIP(hipMemsetAsync(bad, 0, (size_t)nqc * 4, st));
+        if (half) VDB_HIP(launch_split_query16(tv.dt, qprep, nqi, dpad, qhi, qlo, bad, st));
         // pass 0: every score of the first n0 (<= GEMM_CAP) rows is kept; thr0 = K-th best of them
         VDB_HIP(hipMemsetAsync(cnt, 0, (size_t)nqc * 8, st));
         VDB_HIP(hipMemsetD32Async((hipDeviceptr_t)thr1, (int)0xff800000, (size_t)nqc, st));      // -inf
-        VDB_HIP(launch_gemm_thresh(tv0, qprep, nqi, dpad, thr1, 0, 1, (n0 + 127) / 128, cs, ct, cnt, lost, GEMM_CAP, G.n_cu, st));
+        VDB_HIP(gemm(tv0, thr1, 1, (n0 + 127) / 128));
         VDB_HIP(launch_kth_threshold(cs, GEMM_CAP, cnt, 0, GEMM_CAP, K, nullptr, thr0, nqi, st));
-        const float* tau = thr0;
-        if (stride1 > 1) {
-            // pass 1: every stride1-th row tile -> thr1
+        float* tau = thr0;
+        float* spare = thr1;
+        for (long long tiles : level_tiles) {
+            // strided sample of `tiles` row tiles under the current threshold -> next threshold
+            const long long stride = ntiles / tiles;
             VDB_HIP(hipMemsetAsync(cnt, 0, (size_t)nqc * 8, st));
-            VDB_HIP(launch_gemm_thresh(tv, qprep, nqi, dpad, thr0, 0, stride1, tiles1, cs, ct, cnt, lost, GEMM_CAP, G.n_cu, st));
-            VDB_HIP(launch_kth_threshold(cs, GEMM_CAP, cnt, 0, GEMM_CAP, K, thr0, thr1, nqi, st));
-            tau = thr1;
+            VDB_HIP(gemm(tv, tau, stride, ntiles / stride));
+            VDB_HIP(launch_kth_threshold(cs, GEMM_CAP, cnt, 0, GEMM_CAP, K, tau, spare, nqi, st));
+            std::swap(tau, spare);
         }
-        // pass 2: all row tiles
+        // last pass: all row tiles
         VDB_HIP(hipMemsetAsync(cnt, 0, (size_t)nqc * 8, st));
         ProfScope prof;
         if ((rc = prof.begin(st))) return rc;
-        VDB_HIP(launch_gemm_thresh(tv, qprep, nqi, dpad, tau, 0, 1, ntiles, cs, ct, cnt, lost, GEMM_CAP, G.n_cu, st));
+        VDB_HIP(gemm(tv, tau, 1, ntiles));
         if ((rc = prof.end(st))) return rc;
-        VDB_HIP(launch_finalize_flat(tv, qprep, qinfo, nqi, dpad, g, k, cs, ct, cnt, GEMM_CAP, tau, lost,
+        VDB_HIP(launch_finalize_flat(tv, qprep, qinfo, nqi, dpad, g, k, cs, ct, cnt, GEMM_CAP, tau, lost, bad, fb,
                                      out_ids + (size_t)q0 * k, out_scores + (size_t)q0 * k, out_counts + q0,
                                      ne, G.d_counters, st));
         VDB_HIP(launch_exact(tv, qprep, nqi, dpad, g, Gx, k, cs, ct,
@@ -332,7 +361,7 @@ static int search_core(Table& t, int64_t nq, const float* q_dev, int k, long lon
     SelGeom g = sel_geom(k);
     if (G.tune_waves > 0 && G.tune_waves < g.W) g.W = G.tune_waves;
     // engine_config.use_blas_threshold: batches at least this large take the GEMM path
-    const bool gemm = nq >= G.use_blas_threshold && t.dtype == VDB_F32 && tv.n >= 65536 && g.K <= 256 &&
+    const bool gemm = nq >= G.use_blas_threshold && tv.n >= 65536 && g.K <= 256 &&
                       G.tune_gemm != 0;
     if (gemm) G.batched_queries += nq;
     if (gemm) return search_gemm_path(tv, g, t.dpad, nq, q_dev, k, out_ids, out_scores, out_counts, st, ws);
@@ -455,7 +484,7 @@ int vdb_shutdown(void) {
     std::lock_guard<std::mutex> lk(G.mu);
     for (auto& w : G.free_ws) {
         for (DevBuf* b : {&w->qprep, &w->qinfo, &w->cand_s, &w->cand_t, &w->need_exact, &w->q_raw,
-                          &w->o_ids, &w->o_scores, &w->o_counts, &w->small, &w->cand_h})
+                          &w->o_ids, &w->o_scores, &w->o_counts, &w->small, &w->cand_h, &w->q16})
             if (b->p) (void)hipFree(b->p);
         if (w->stream) (void)hipStreamDestroy(w->stream);
         if (w->done) (void)hipEventDestroy(w->done);
@@ -484,6 +513,8 @@ int vdb_set_option(const char* key, double value) {
     else if (k == "scan_blocks_per_cu") { if (value < 0 || value > 32) return fail(VDB_EINVAL, "scan_blocks_per_cu not in [0,32]"); G.tune_bpc = (int)value; }
     else if (k == "scan_contiguous") G.tune_contig = value != 0;
     else if (k == "gemm_path") G.tune_gemm = value != 0;
+    else if (k == "gemm_split_f16") G.tune_split_f16 = value != 0;
+    else if (k == "gemm16_variant") set_gemm16_variant((int)value);
     else return fail(VDB_EINVAL, "unknown option: " + k);
     set_scan_tune(G.tune_nt, G.tune_waves, G.tune_bpc, G.tune_contig);
     return VDB_OK;

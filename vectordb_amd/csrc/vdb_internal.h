@@ -72,10 +72,16 @@ hipError_t launch_finalize(const TableView& t, const float* qprep, const QInfo* 
 
 // Same for the batched path: one unsorted candidate array of `cap` slots per query, `cnt[q]`
 // appended, every non-candidate row known to have a fast key <= tau[q].
+// Terms the batched path adds to the fp32 scoring-error bound of the certificate.
+struct FlatBound {
+    double dd_mult = 1.0;     // accumulation chain length in units of d (2 when hi and lo parts are summed)
+    double extra_rel = 0.0;   // relative error of the query as the MFMA sees it (x ||x|| ||q||)
+    double extra_abs = 0.0;   // absolute error per unit of ||x|| (fp16 subnormal spacing)
+};
 hipError_t launch_finalize_flat(const TableView& t, const float* qprep, const QInfo* qinfo, int64_t nq,
                                 int dpad, const SelGeom& g, int k,
                                 const float* cand_s, const long long* cand_t, const int* cnt, int cap,
-                                const float* tau, const int* lost,
+                                const float* tau, const int* lost, const int* bad, const FlatBound& fb,
                                 long long* out_ids, float* out_scores, int* out_counts,
                                 int* need_exact, long long* counters, hipStream_t st);
 
@@ -85,6 +91,14 @@ hipError_t launch_gemm_thresh(const TableView& t, const float* qprep, int nq, in
                               long long tile0, long long tile_stride, long long ntiles,
                               float* cand_s, long long* cand_t, int* cnt, int* lost, int cap,
                               int n_cu, hipStream_t st);
+hipError_t launch_gemm16_thresh(const TableView& t, const unsigned short* qhi, const unsigned short* qlo,
+                                int split, int nq, int dpad, const float* thr,
+                                long long tile0, long long tile_stride, long long ntiles,
+                                float* cand_s, long long* cand_t, int* cnt, int* lost, int cap,
+                                int n_cu, hipStream_t st);
+void set_gemm16_variant(int v);
+hipError_t launch_split_query16(int dt, const float* qprep, int nq, int dpad, unsigned short* hi,
+                                unsigned short* lo, int* bad, hipStream_t st);
 // thr_out[q] = max(thr_in[q], K-th best key among query q's candidates); candidates of query q start
 // at cand_s + q*stride and number cnt[q] (capped at cap), or count_all when cnt is null.
 hipError_t launch_kth_threshold(const float* cand_s, long long stride, const int* cnt, long long count_all,
