@@ -68,7 +68,10 @@ int vdb_shutdown(void);
  * "cache_capacity_gb" (:42, HBM budget for all tables, 0 = unlimited),
  * "insert_buffer_size_gb" (:19, pinned host staging for host inserts).
  * Launch tunables of the scan kernel (defaults are the measured best): "scan_nt",
- * "scan_waves", "scan_blocks_per_cu", "scan_contiguous". */
+ * "scan_waves", "scan_blocks_per_cu", "scan_contiguous".
+ * Batched path: "gemm_path" (0 sends every batch through the scan path), "gemm_split_f16"
+ * (1 splits fp32 queries into hi + lo halves for fp16 tables as is always done for bf16),
+ * "gemm16_variant" (0 = LDS-tiled kernel, 1 = register-streaming kernel). */
 int vdb_set_option(const char* key, double value);
 const char* vdb_last_error(void);
 
@@ -106,6 +109,17 @@ int vdb_synth_fill_dev(float* out_dev, int64_t n, int64_t dim, uint64_t seed, in
 /* copy stored rows [first, first+n) back to the host as fp32 (tests and snapshots);
  * out_rows [n, dim], out_ids [n]; either may be NULL */
 int vdb_fetch_rows(const char* name, int64_t first, int64_t n, float* out_rows, int64_t* out_ids);
+
+/* ---- snapshots: the engine-side part of db_config.primary_path / preload_table
+ * (/root/reference/server_config.yaml:12, :22), which the Milvus server the reference talks to
+ * uses to keep tables across restarts and to bring them into memory at start-up.
+ * vdb_save_table writes the stored (quantised, for COSINE normalised) rows, ids and row norms of
+ * one table to `path` (written under a temporary name, then renamed).  vdb_load_table creates
+ * table `name` from such a file: VDB_EEXISTS if the name is taken, VDB_ENOTFOUND if the file
+ * cannot be opened, VDB_EINVAL if it is not a complete snapshot.  A loaded table answers every
+ * search with the same ids and scores as the table that was saved. */
+int vdb_save_table(const char* name, const char* path);
+int vdb_load_table(const char* name, const char* path);
 
 /* ---- search: replaces search_vectors(table_name, query_records, top_k, nprobe) (app.py:384-391)
  * queries: [nq, dim] fp32.  Outputs, per query q: out_counts[q] = min(k, rows) hits, best first,

@@ -128,6 +128,16 @@ def create_app(client: Milvus = None, store: MetaStore = None) -> Flask:
             print("Error while deleting table", exc)
         return "Table deleted" if all_ok else "Problem with deleting table. See server log for details"
 
+    @app.route("/snapshot")
+    def snapshot_db():
+        # no counterpart among the reference's routes: its external engine wrote every insert to
+        # db_config.primary_path by itself; the in-process engine writes a table when asked to
+        name = request.args.get("dbname")
+        status = engine().snapshot(name)
+        if status.code != 0:
+            return "Error: " + status.message, 400
+        return "Snapshot written"
+
     @app.route("/insert", methods=["PUT"])
     def insert_vector():
         name = request.args.get("dbname")

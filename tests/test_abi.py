@@ -94,3 +94,15 @@ def test_config_reads_reference_style_file(tmp_path):
     with pytest.raises(ValueError):
         parse_config({"gpu_resource_config": {"search_resources": ["cpu0"]}})
     assert isinstance(parse_config(None), EngineConfig)
+
+
+def test_snapshot_file_names_stay_inside_primary_path():
+    from vectordb_amd import milvus as M
+    from vectordb_amd._lib import VdbError
+    assert M.snapshot_path("/data", "demo_1") == "/data/demo_1" + M.SNAPSHOT_SUFFIX
+    for bad in ("../x", "a/b", "", ".hidden", "a..b", "x" * 300):
+        with pytest.raises(VdbError):
+            M.snapshot_path("/data", bad)
+    # not connected: the snapshot calls answer with a status like every other call
+    m = M.Milvus()
+    assert not m.snapshot("demo").OK() and not m.preload_table("demo").OK()

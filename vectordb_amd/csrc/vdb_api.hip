@@ -706,6 +706,131 @@ int vdb_fetch_rows(const char* name, int64_t first, int64_t n, float* out_rows, 
     return VDB_OK;
 }
 
+// ---------------------------------------------------------------------------------- snapshots
+// File layout (little endian): SnapHeader, then rows[rows * m * 16], ids[rows * 8], n2[rows * 4].
+// The stored rows are already quantised (and normalised for COSINE), so a loaded table is
+// bit-identical to the saved one and searches on it return the same ids and scores.
+struct SnapHeader {
+    char     magic[8];      // "VDBSNAP1"
+    int64_t  dim;
+    int32_t  metric, dtype;
+    int64_t  rows;
+    int32_t  m;
+    float    max_n2;
+};
+
+static const size_t SNAP_CHUNK = (size_t)64 << 20;
+
+struct HostPinned {
+    void* p = nullptr;
+    ~HostPinned() { if (p) (void)hipHostFree(p); }
+};
+struct FileCloser {
+    FILE* f = nullptr;
+    ~FileCloser() { if (f) fclose(f); }
+};
+
+static int snap_write(FILE* f, const char* dev, size_t bytes, void* bounce) {
+    for (size_t o = 0; o < bytes; o += SNAP_CHUNK) {
+        const size_t nb = bytes - o < SNAP_CHUNK ? bytes - o : SNAP_CHUNK;
+        VDB_HIP(hipMemcpy(bounce, dev + o, nb, hipMemcpyDeviceToHost));
+        if (fwrite(bounce, 1, nb, f) != nb) return fail(VDB_EINVAL, "short write to snapshot file");
+    }
+    return VDB_OK;
+}
+
+static int snap_read(FILE* f, char* dev, size_t bytes, void* bounce) {
+    for (size_t o = 0; o < bytes; o += SNAP_CHUNK) {
+        const size_t nb = bytes - o < SNAP_CHUNK ? bytes - o : SNAP_CHUNK;
+        if (fread(bounce, 1, nb, f) != nb) return fail(VDB_EINVAL, "snapshot file is truncated");
+        VDB_HIP(hipMemcpy(dev + o, bounce, nb, hipMemcpyHostToDevice));
+    }
+    return VDB_OK;
+}
+
+int vdb_save_table(const char* name, const char* path) {
+    int rc = enter();
+    if (rc) return rc;
+    if (!name || !path || !*path) return fail(VDB_EINVAL, "null table name or path");
+    auto t = find_table(name);
+    if (!t) return fail(VDB_ENOTFOUND, std::string("no such table: ") + name);
+    std::shared_lock<std::shared_mutex> tl(t->mu);
+    if (t->dropped) return fail(VDB_ENOTFOUND, "table was dropped");
+    SnapHeader h;
+    std::memset(&h, 0, sizeof h);
+    std::memcpy(h.magic, "VDBSNAP1", 8);
+    h.dim = t->dim; h.metric = t->metric; h.dtype = t->dtype; h.rows = t->rows; h.m = t->m;
+    VDB_HIP(hipMemcpy(&h.max_n2, t->d_maxn2, sizeof(float), hipMemcpyDeviceToHost));
+    HostPinned hp;
+    VDB_HIP(hipHostMalloc(&hp.p, SNAP_CHUNK, hipHostMallocDefault));
+    const std::string tmp = std::string(path) + ".tmp";
+    {
+        FileCloser fc;
+        fc.f = fopen(tmp.c_str(), "wb");
+        if (!fc.f) return fail(VDB_EINVAL, "cannot open snapshot file for writing: " + tmp);
+        if (fwrite(&h, sizeof h, 1, fc.f) != 1) return fail(VDB_EINVAL, "short write to snapshot file");
+        if (t->rows > 0) {
+            if ((rc = snap_write(fc.f, t->d_rows, (size_t)t->rows * t->m * 16, hp.p))) return rc;
+            if ((rc = snap_write(fc.f, (const char*)t->d_ids, (size_t)t->rows * sizeof(long long), hp.p))) return rc;
+            if ((rc = snap_write(fc.f, (const char*)t->d_n2, (size_t)t->rows * sizeof(float), hp.p))) return rc;
+        }
+        if (fflush(fc.f) != 0) return fail(VDB_EINVAL, "flush of snapshot file failed");
+    }
+    // a reader never sees a half-written snapshot under the final name
+    if (std::rename(tmp.c_str(), path) != 0) return fail(VDB_EINVAL, std::string("cannot rename snapshot to ") + path);
+    return VDB_OK;
+}
+
+int vdb_load_table(const char* name, const char* path) {
+    int rc = enter();
+    if (rc) return rc;
+    if (!name || !*name || !path || !*path) return fail(VDB_EINVAL, "null table name or path");
+    FileCloser fc;
+    fc.f = fopen(path, "rb");
+    if (!fc.f) return fail(VDB_ENOTFOUND, std::string("cannot open snapshot file: ") + path);
+    SnapHeader h;
+    if (fread(&h, sizeof h, 1, fc.f) != 1 || std::memcmp(h.magic, "VDBSNAP1", 8) != 0)
+        return fail(VDB_EINVAL, std::string("not a table snapshot: ") + path);
+    if (h.dim < 1 || h.dim > 16384 || h.rows < 0 ||
+        (h.metric != VDB_METRIC_L2 && h.metric != VDB_METRIC_IP && h.metric != VDB_METRIC_COSINE) ||
+        (h.dtype != VDB_F32 && h.dtype != VDB_BF16 && h.dtype != VDB_F16))
+        return fail(VDB_EINVAL, "snapshot header holds values out of range");
+    const int epl = elems_per_unit(h.dtype);
+    if (h.m != (int)((h.dim + epl - 1) / epl)) return fail(VDB_EINVAL, "snapshot row stride does not match its dimension");
+    if (!(h.max_n2 >= 0.0f)) return fail(VDB_EINVAL, "snapshot header holds values out of range");
+    // the payload must be as long as the header promises before any device memory is taken
+    const long long payload = (long long)h.rows * ((long long)h.m * 16 + 12);
+    if (fseek(fc.f, 0, SEEK_END) != 0) return fail(VDB_EINVAL, "cannot seek in snapshot file");
+    const long long fsize = ftell(fc.f);
+    if (fsize != (long long)sizeof h + payload) return fail(VDB_EINVAL, "snapshot file length does not match its header");
+    if (fseek(fc.f, (long)sizeof h, SEEK_SET) != 0) return fail(VDB_EINVAL, "cannot seek in snapshot file");
+
+    if ((rc = vdb_create_table(name, h.dim, h.metric, h.dtype))) return rc;
+    auto t = find_table(name);
+    if (!t) return fail(VDB_ESTATE, "table vanished while loading");
+    {
+        std::unique_lock<std::shared_mutex> tl(t->mu);
+        if (h.rows > 0) {
+            HostPinned hp;
+            rc = table_alloc(*t, h.rows);
+            if (!rc && hipHostMalloc(&hp.p, SNAP_CHUNK, hipHostMallocDefault) != hipSuccess)
+                rc = fail(VDB_ENOMEM, "cannot allocate the host staging buffer");
+            if (!rc) rc = snap_read(fc.f, t->d_rows, (size_t)h.rows * h.m * 16, hp.p);
+            if (!rc) rc = snap_read(fc.f, (char*)t->d_ids, (size_t)h.rows * sizeof(long long), hp.p);
+            if (!rc) rc = snap_read(fc.f, (char*)t->d_n2, (size_t)h.rows * sizeof(float), hp.p);
+        }
+        if (!rc && hipMemcpy(t->d_maxn2, &h.max_n2, sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+            rc = fail(VDB_EHIP, "cannot store the row-norm bound");
+        if (!rc) t->rows = h.rows;
+    }
+    if (rc) {
+        const std::string keep = tl_error;
+        (void)vdb_drop_table(name);
+        return fail(rc, keep);
+    }
+    return VDB_OK;
+}
+
 static int check_search_args(const char* name, int64_t nq, const void* q, int k, const void* a,
                              const void* b, const void* c) {
     if (!name || nq < 0) return fail(VDB_EINVAL, "bad argument");

@@ -6,6 +6,7 @@ All arithmetic happens in libvdb.so on the GPU; this module only marshals argume
 from __future__ import annotations
 
 import ctypes as C
+import os
 import threading
 from typing import Optional, Tuple
 
@@ -96,6 +97,13 @@ class Engine:
         ids = np.empty((n,), dtype=np.int64)
         check(self.lib.vdb_fetch_rows(_name(name), int(first), int(n), rows.ctypes.data, ids.ctypes.data))
         return rows, ids
+
+    # ---- snapshots
+    def save_table(self, name: str, path: str) -> None:
+        check(self.lib.vdb_save_table(_name(name), os.fsencode(path)))
+
+    def load_table(self, name: str, path: str) -> None:
+        check(self.lib.vdb_load_table(_name(name), os.fsencode(path)))
 
     # ---- search
     def search(self, name: str, queries, k: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:

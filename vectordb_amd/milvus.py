@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import enum
 import os
+import re
 import threading
 from typing import Any, Dict, List, Optional, Sequence, Tuple
 
@@ -85,6 +86,37 @@ _DTYPE_BY_NAME = {"f32": _lib.F32, "fp32": _lib.F32, "float32": _lib.F32,
 _engine_lock = threading.Lock()
 _engine: Optional[Engine] = None
 
+SNAPSHOT_SUFFIX = ".vdbsnap"
+_TABLE_FILE_RE = re.compile(r"^[A-Za-z0-9_][A-Za-z0-9_.-]{0,254}$")
+
+
+def snapshot_path(primary_path: str, table_name: str) -> str:
+    """File of `table_name` under db_config.primary_path (/root/reference/server_config.yaml:12).
+    Names that could leave the directory are refused."""
+    if not _TABLE_FILE_RE.match(table_name) or ".." in table_name:
+        raise VdbError(_lib.EINVAL, "table name cannot be used as a snapshot file name: %r" % (table_name,))
+    return os.path.join(primary_path, table_name + SNAPSHOT_SUFFIX)
+
+
+def _preload(engine: Engine, cfg: EngineConfig) -> List[str]:
+    """db_config.preload_table (/root/reference/server_config.yaml:22): '*' loads every snapshot
+    in primary_path, otherwise the listed tables.  Returns the names loaded; a listed table
+    without a snapshot is skipped (a fresh deployment has none yet)."""
+    if not cfg.preload_table or not os.path.isdir(cfg.primary_path):
+        return []
+    if "*" in cfg.preload_table:
+        names = sorted(f[:-len(SNAPSHOT_SUFFIX)] for f in os.listdir(cfg.primary_path)
+                       if f.endswith(SNAPSHOT_SUFFIX))
+    else:
+        names = list(cfg.preload_table)
+    loaded = []
+    for name in names:
+        path = snapshot_path(cfg.primary_path, name)
+        if os.path.exists(path) and not engine.has_table(name):
+            engine.load_table(name, path)
+            loaded.append(name)
+    return loaded
+
 
 def _get_engine(config: Optional[EngineConfig]) -> Engine:
     global _engine
@@ -95,7 +127,9 @@ def _get_engine(config: Optional[EngineConfig]) -> Engine:
                 raise VdbError(_lib.ENOGPU, "gpu_resource_config.enable is false and there is no CPU engine")
             rank = int(os.environ.get("LOCAL_RANK", "0"))
             device = int(os.environ.get("VDB_DEVICE", cfg.device_for_rank(rank)))
-            _engine = Engine(device=device, config=cfg)
+            engine = Engine(device=device, config=cfg)
+            _preload(engine, cfg)
+            _engine = engine
         return _engine
 
 
@@ -167,7 +201,13 @@ class Milvus:
 
     def delete_table(self, table_name: str) -> Status:
         try:
-            self._eng().drop_table(table_name)
+            eng = self._eng()
+            eng.drop_table(table_name)
+            # a dropped table must not come back at the next start
+            try:
+                os.remove(snapshot_path(eng.config.primary_path, table_name))
+            except (OSError, VdbError):
+                pass
             return Status()
         except Exception as exc:
             return self._status(exc)
@@ -188,6 +228,28 @@ class Milvus:
                               "row_count": info["rows"]}
         except Exception as exc:
             return self._status(exc), None
+
+    # -- snapshots -------------------------------------------------------------------------
+    def snapshot(self, table_name: str) -> Status:
+        """Write `table_name` to db_config.primary_path so that a restarted process can preload it
+        (the external engine persisted every insert to that directory by itself)."""
+        try:
+            eng = self._eng()
+            os.makedirs(eng.config.primary_path, exist_ok=True)
+            eng.save_table(table_name, snapshot_path(eng.config.primary_path, table_name))
+            return Status()
+        except Exception as exc:
+            return self._status(exc)
+
+    def preload_table(self, table_name: str, timeout: Optional[int] = None) -> Status:
+        """Bring `table_name` into HBM from its snapshot unless it is already resident."""
+        try:
+            eng = self._eng()
+            if not eng.has_table(table_name):
+                eng.load_table(table_name, snapshot_path(eng.config.primary_path, table_name))
+            return Status()
+        except Exception as exc:
+            return self._status(exc)
 
     # -- append ----------------------------------------------------------------------------
     def insert(self, table_name: str, records: Sequence[Sequence[float]], ids: Optional[Sequence[int]] = None,
