@@ -8,6 +8,9 @@ A step = one query scored against every stored row, exact top-10 returned (ids +
 device memory.  With N > 1 the 10M rows are row-sharded over the N ranks (strong scaling): each
 rank scans its shard, one RCCL all-gather exchanges the per-rank top-10 records, every rank
 merges them.  Inputs (table and queries) are resident in HBM before the timed region.
+Single-query steps are issued round-robin on --streams HIP streams (default 2), as the requests
+of concurrent clients are: the library runs the table scans strictly one after the other, and the
+short kernels and the collective around one scan overlap with the next query's scan.
 
 Prints ONE JSON line (rank 0) with the throughput, the roofline of the dominant kernel (the scan:
 algorithmic bytes = rows_per_gpu * dim * 4 per launch over its HIP-event duration inside the
@@ -89,6 +92,11 @@ def main() -> None:
     ap.add_argument("--nq", type=int, default=1, help="queries per step")
     ap.add_argument("--metric", default="cosine", choices=sorted(METRICS))
     ap.add_argument("--dtype", default="f32", choices=sorted(DTYPES))
+    ap.add_argument("--streams", type=int, default=2,
+                    help="queries in flight: step i runs on HIP stream i %% streams, as the requests of "
+                         "concurrent clients do; the library runs the table scans one after the other and "
+                         "overlaps the short kernels and the collective around them")
+    ap.add_argument("--scan-serialize", type=int, default=1, help="0 lets scans of different streams overlap")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="0 disables the CPU baseline")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (nccl = RCCL; gloo rehearses the path on fewer GPUs)")
@@ -114,6 +122,7 @@ def main() -> None:
             dist.init_process_group("gloo")
 
     eng = Engine(device=dev_index)
+    eng.set_option("scan_serialize", args.scan_serialize)
     dt, esz = DTYPES[args.dtype]
     metric = METRICS[args.metric]
     first, last = shard_range(args.rows, world, rank)
@@ -130,10 +139,16 @@ def main() -> None:
     stream = torch.cuda.current_stream()
     eng.synth_fill_dev(queries.data_ptr(), total * args.nq, args.dim, seed=1, first_row=0, stream=stream.cuda_stream)
     local_search, merge = gpu_backend(eng, table, args.nq, args.k, metric)
-    searcher = ShardedSearcher(args.nq, args.k, dev, local_search, merge)
+    # batches keep the GPU busy on their own; single queries are pipelined over several streams
+    n_streams = max(1, args.streams) if args.nq == 1 else 1
+    searchers = [ShardedSearcher(args.nq, args.k, dev, local_search, merge) for _ in range(n_streams)]
+    streams = [stream] if n_streams == 1 else [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
+    torch.cuda.synchronize()
 
     def step(i: int):
-        return searcher.search(queries[i * args.nq:(i + 1) * args.nq])
+        slot = i % n_streams
+        with torch.cuda.stream(streams[slot]):
+            return searchers[slot].search(queries[i * args.nq:(i + 1) * args.nq])
 
     def fence():
         torch.cuda.synchronize()
@@ -187,6 +202,7 @@ def main() -> None:
                             % (args.rows, args.dim, args.dtype, args.metric, args.k, args.nq, world),
                 "rows_per_gpu": n_local,
                 "parallelism": "row-shard x%d + RCCL all-gather of top-k records" % world if world > 1 else "single GPU",
+                "streams": n_streams,
                 "table_fill_s": round(t_fill, 2),
                 "exact_fallbacks": fallbacks,
                 "queries_counted": queries_done,

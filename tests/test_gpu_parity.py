@@ -424,3 +424,36 @@ def test_streaming_16bit_gemm_variant_parity(engine, table_name):
         _check(engine, table_name, stored, ids, q, 10, O.L2)
     finally:
         engine.set_option("gemm16_variant", 0)
+
+
+@pytest.mark.parametrize("ordered", [1, 0])
+def test_queries_in_flight_on_several_streams(engine, table_name, ordered):
+    """Single queries issued round-robin on three HIP streams (the pattern of concurrent clients):
+    every answer equals the oracle's whether the library orders the scans or lets them overlap."""
+    import torch
+    n, d, k, nq = 50_000, 96, 10, 24
+    rows = cases.make_rows("synth", 91, n, d)
+    ids = cases.make_ids("hash", 91, n)
+    stored = _load(engine, table_name, rows, ids, _lib.METRIC_COSINE, _lib.F32)
+    q = cases.make_queries("synth", 91, nq, d, rows)
+    qd = torch.from_numpy(q).cuda()
+    out_ids = torch.full((nq, k), -7, dtype=torch.int64, device="cuda")
+    out_sc = torch.zeros((nq, k), dtype=torch.float32, device="cuda")
+    out_cnt = torch.zeros((nq,), dtype=torch.int32, device="cuda")
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    torch.cuda.synchronize()
+    engine.set_option("scan_serialize", ordered)
+    try:
+        for i in range(nq):
+            st = streams[i % 3]
+            engine.search_dev(table_name, 1, qd[i:i + 1].data_ptr(), k, out_ids[i:i + 1].data_ptr(),
+                              out_sc[i:i + 1].data_ptr(), out_cnt[i:i + 1].data_ptr(), st.cuda_stream)
+        torch.cuda.synchronize()
+    finally:
+        engine.set_option("scan_serialize", 1)
+    want = O.search(stored, ids, q, k, O.COSINE)
+    got_ids, got_sc = out_ids.cpu().numpy(), out_sc.cpu().numpy()
+    assert out_cnt.cpu().numpy().tolist() == [k] * nq
+    for qi, (wi, ws) in enumerate(want):
+        assert np.array_equal(got_ids[qi], wi)
+        assert np.array_equal(got_sc[qi].view(np.uint32), ws.view(np.uint32))

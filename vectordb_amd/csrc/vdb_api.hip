@@ -89,6 +89,12 @@ struct Global {
     std::mutex prof_mu;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
+    // order of table scans issued on different streams (guarded by chain_mu)
+    std::mutex chain_mu;
+    int scan_serialize = 1;
+    hipEvent_t chain_ev[16] = {};
+    int chain_head = -1;
+    hipStream_t chain_last = nullptr;
 };
 static Global G;
 
@@ -229,10 +235,29 @@ static int search_scan_path(const TableView& tv, const SelGeom& g, int dpad, int
         long long* ct = (long long*)ws.cand_t.p;
         int* ne = (int*)ws.need_exact.p;
         VDB_HIP(launch_prep_query(q_dev + (size_t)q0 * tv.d, nqi, tv.d, dpad, tv.metric, qprep, qinfo, ne, st));
-        ProfScope prof;
-        if ((rc = prof.begin(st))) return rc;
-        VDB_HIP(launch_scan(tv, qprep, nqi, dpad, g, Gx, cs, ct, (float*)ws.cand_h.p, st));
-        if ((rc = prof.end(st))) return rc;
+        {
+            // A scan saturates HBM on its own, so scans issued on different streams run one after
+            // the other (two at once would only evict each other's cache lines), while the short
+            // kernels before and after a scan overlap with the scans of the other streams.
+            std::unique_lock<std::mutex> chain(G.chain_mu);
+            const bool ordered = G.scan_serialize != 0;
+            if (!ordered) chain.unlock();
+            if (ordered) {
+                if (G.chain_head >= 0 && G.chain_last != st)
+                    VDB_HIP(hipStreamWaitEvent(st, G.chain_ev[G.chain_head], 0));
+            }
+            ProfScope prof;
+            if ((rc = prof.begin(st))) return rc;
+            VDB_HIP(launch_scan(tv, qprep, nqi, dpad, g, Gx, cs, ct, (float*)ws.cand_h.p, st));
+            if ((rc = prof.end(st))) return rc;
+            if (ordered) {
+                const int slot = (G.chain_head + 1) % 16;
+                if (!G.chain_ev[slot]) VDB_HIP(hipEventCreateWithFlags(&G.chain_ev[slot], hipEventDisableTiming));
+                VDB_HIP(hipEventRecord(G.chain_ev[slot], st));
+                G.chain_head = slot;
+                G.chain_last = st;
+            }
+        }
         VDB_HIP(launch_finalize(tv, qprep, qinfo, nqi, dpad, g, Gx * g.W, k, cs, ct, (const float*)ws.cand_h.p,
                                 out_ids + (size_t)q0 * k, out_scores + (size_t)q0 * k, out_counts + q0,
                                 ne, G.d_counters, st));
@@ -495,6 +520,17 @@ int vdb_shutdown(void) {
     G.stage_rows = DevBuf(); G.stage_ids = DevBuf();
     if (G.insert_stream) (void)hipStreamDestroy(G.insert_stream);
     G.insert_stream = nullptr;
+    {
+        std::lock_guard<std::mutex> cl(G.chain_mu);
+        for (hipEvent_t& e : G.chain_ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+        G.chain_head = -1; G.chain_last = nullptr;
+    }
+    {
+        std::lock_guard<std::mutex> pl(G.prof_mu);
+        for (auto& pr : G.prof_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+        for (auto& pr : G.prof_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+        G.prof_pool.clear(); G.prof_events.clear();
+    }
     if (G.d_counters) (void)hipFree(G.d_counters);
     G.d_counters = nullptr;
     G.inited = false;
@@ -512,6 +548,7 @@ int vdb_set_option(const char* key, double value) {
     else if (k == "scan_waves") { if (value < 0 || value > 16) return fail(VDB_EINVAL, "scan_waves not in [0,16]"); G.tune_waves = (int)value; }
     else if (k == "scan_blocks_per_cu") { if (value < 0 || value > 32) return fail(VDB_EINVAL, "scan_blocks_per_cu not in [0,32]"); G.tune_bpc = (int)value; }
     else if (k == "scan_contiguous") G.tune_contig = value != 0;
+    else if (k == "scan_serialize") { std::lock_guard<std::mutex> cl(G.chain_mu); G.scan_serialize = value != 0; }
     else if (k == "gemm_path") G.tune_gemm = value != 0;
     else if (k == "gemm_split_f16") G.tune_split_f16 = value != 0;
     else if (k == "gemm16_variant") set_gemm16_variant((int)value);
