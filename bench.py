@@ -171,6 +171,20 @@ def main() -> None:
     last_ids = out.ids.cpu().numpy().copy()
     last_scores = out.scores.cpu().numpy().copy()
 
+    # request latency through the host entry point (vdb_search: H2D of the query, the same kernels,
+    # D2H of ids and scores), one blocking call at a time -- outside the timed region
+    host_lat = None
+    if world == 1 and args.nq == 1:
+        q_host = queries[:64].cpu().numpy()
+        lat = []
+        for i in range(64):
+            t1 = time.perf_counter()
+            eng.search(table, q_host[i:i + 1], args.k)
+            lat.append((time.perf_counter() - t1) * 1e3)
+        lat = np.sort(np.array(lat[4:]))
+        host_lat = {"p50": float(np.percentile(lat, 50)), "p99": float(np.percentile(lat, 99)),
+                    "calls": int(lat.size), "what": "blocking vdb_search from host memory, one query per call"}
+
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -219,6 +233,7 @@ def main() -> None:
                 "avg_launch_ms": avg_scan_s * 1e3,
                 "launches_timed": scan_launches,
             },
+            "host_latency_ms": host_lat,
             "sample_result": {"ids": [int(x) for x in last_ids[0][:3]], "scores": [float(x) for x in last_scores[0][:3]]},
         }
         # HBM bytes per scan launch from the PMC pass (rocprofv3 --pmc FETCH_SIZE, a run of its own,
