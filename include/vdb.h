@@ -68,7 +68,9 @@ int vdb_shutdown(void);
  * "cache_capacity_gb" (:42, HBM budget for all tables, 0 = unlimited),
  * "insert_buffer_size_gb" (:19, pinned host staging for host inserts).
  * Launch tunables of the scan kernel (defaults are the measured best): "scan_nt",
- * "scan_waves", "scan_blocks_per_cu", "scan_contiguous".
+ * "scan_waves", "scan_blocks_per_cu", "scan_contiguous"; "scan_serialize" (1 = scans issued on
+ * different streams run one after the other, chained by events, while the short kernels around
+ * them overlap; 0 = scans of different streams may overlap).
  * Batched path: "gemm_path" (0 sends every batch through the scan path), "gemm_split_f16"
  * (1 splits fp32 queries into hi + lo halves for fp16 tables as is always done for bf16),
  * "gemm16_variant" (0 = LDS-tiled kernel, 1 = register-streaming kernel). */
