@@ -73,7 +73,7 @@ int vdb_shutdown(void);
  * them overlap; 0 = scans of different streams may overlap).
  * Batched path: "gemm_path" (0 sends every batch through the scan path), "gemm_split_f16"
  * (1 splits fp32 queries into hi + lo halves for fp16 tables as is always done for bf16),
- * "gemm16_variant" (0 = LDS-tiled kernel, 1 = register-streaming kernel). */
+ * "gemm16_variant" (0 = chosen by shape, 1 = register-streaming kernel, 11 = LDS-tiled kernel). */
 int vdb_set_option(const char* key, double value);
 const char* vdb_last_error(void);
 

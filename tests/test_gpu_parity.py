@@ -411,19 +411,35 @@ def test_batched_gemm_path_16bit_parity(engine, table_name, metric, dtype, d, nq
             engine.set_option("gemm_split_f16", 0)
 
 
-def test_streaming_16bit_gemm_variant_parity(engine, table_name):
-    """The alternative 16-bit batched kernel (row fragments straight to registers) stays selectable
-    through the `gemm16_variant` option and must give the same exact results."""
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("variant", [1, 11])
+def test_both_16bit_gemm_kernels_parity(engine, table_name, variant, dtype):
+    """The library picks one of two 16-bit batched kernels by shape (LDS-staged tile kernel or
+    row fragments streamed straight to registers); forced through the `gemm16_variant` option
+    each must give the same exact results for split (bf16) and unsplit (fp16) queries."""
     n, d, nq = 70_000, 200, 40
     rows = cases.make_rows("synth", 41, n, d)
     ids = cases.make_ids("hash", 41, n)
     q = cases.make_queries("synth", 41, nq, d, rows)
-    stored = _load(engine, table_name, rows, ids, O.L2, O.BF16)
-    engine.set_option("gemm16_variant", 1)
+    stored = _load(engine, table_name, rows, ids, O.L2, cases.DTYPES[dtype])
+    engine.set_option("gemm16_variant", variant)
     try:
         _check(engine, table_name, stored, ids, q, 10, O.L2)
     finally:
         engine.set_option("gemm16_variant", 0)
+
+
+def test_wide_batch_takes_the_streaming_kernel(engine, table_name):
+    """More than two query tiles (nq > 256) on an fp16 table: the shape rule selects the streaming
+    kernel; results stay exact."""
+    n, d, nq = 66_000, 64, 300
+    rows = cases.make_rows("synth", 43, n, d)
+    ids = cases.make_ids("index", 43, n)
+    q = cases.make_queries("synth", 43, nq, d, rows)
+    stored = _load(engine, table_name, rows, ids, O.IP, O.F16)
+    before = engine.stats()[2]
+    _check(engine, table_name, stored, ids, q, 10, O.IP)
+    assert engine.stats()[2] - before == nq
 
 
 @pytest.mark.parametrize("ordered", [1, 0])

@@ -1,41 +1,60 @@
 #!/usr/bin/env python3
-"""A/B of the two 16-bit batched GEMM kernels (gemm16_variant 0 = LDS tile, 1 = streaming) for
-several batch sizes and metrics, interleaved in one process (GPU only)."""
-import os, sys, statistics
-import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from vectordb_amd import _lib
-from vectordb_amd.engine import Engine
+"""A/B of the 16-bit batched GEMM kernels for several batch sizes, interleaved in one process
+(GPU only).  gemm16_variant: 0 = LDS tile kernel with its default register-ring depth,
+11..13 = the same kernel with ring depth 1..3, 1 = streaming kernel.
+Environment: ROWS, DTYPE (f16|bf16), METRICS (comma list), VARIANTS (comma list), NQS."""
+import os
+import statistics
+import sys
+import time
 
-rows, dim = int(os.environ.get("ROWS", 20_000_000)), 768
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vectordb_amd import _lib  # noqa: E402
+from vectordb_amd.engine import Engine  # noqa: E402
+
+rows, dim = int(os.environ.get("ROWS", 20_000_000)), int(os.environ.get("DIM", 768))
+dtype = {"f16": _lib.F16, "bf16": _lib.BF16}[os.environ.get("DTYPE", "f16")]
+metrics = os.environ.get("METRICS", "l2").split(",")
+variants = [int(v) for v in os.environ.get("VARIANTS", "0,1").split(",")]
+nqs = [int(v) for v in os.environ.get("NQS", "128,256,1024").split(",")]
+codes = {"l2": _lib.METRIC_L2, "cosine": _lib.METRIC_COSINE, "ip": _lib.METRIC_IP}
 eng = Engine(0)
 st = torch.cuda.current_stream().cuda_stream
-for metric, mname in ((_lib.METRIC_L2, "l2"), (_lib.METRIC_COSINE, "cosine")):
+for mname in metrics:
     name = "ab_" + mname
-    eng.create_table(name, dim, metric, _lib.F16)
+    eng.create_table(name, dim, codes[mname], dtype)
     eng.reserve(name, rows)
     eng.insert_synthetic(name, rows, 0, 0)
-    for nq in (128, 256, 1024):
+    for nq in nqs:
         q = torch.empty((nq, dim), dtype=torch.float32, device="cuda")
         eng.synth_fill_dev(q.data_ptr(), nq, dim, 1, 0, st)
         oi = torch.empty((nq, 10), dtype=torch.int64, device="cuda")
         os_ = torch.empty((nq, 10), dtype=torch.float32, device="cuda")
         oc = torch.empty((nq,), dtype=torch.int32, device="cuda")
-        res = {0: [], 1: []}
+        res = {v: [] for v in variants}
+        ref = None
         for rnd in range(3):
-            for v in (0, 1):
+            for v in variants:
                 eng.set_option("gemm16_variant", v)
                 eng.search_dev(name, nq, q.data_ptr(), 10, oi.data_ptr(), os_.data_ptr(), oc.data_ptr(), st)
-                torch.cuda.synchronize(); eng.prof_read(); eng.prof_enable(True)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
                 for _ in range(2):
                     eng.search_dev(name, nq, q.data_ptr(), 10, oi.data_ptr(), os_.data_ptr(), oc.data_ptr(), st)
-                torch.cuda.synchronize(); eng.prof_enable(False)
-                ms, n = eng.prof_read()
-                res[v].append(ms / n)
+                torch.cuda.synchronize()
+                res[v].append((time.perf_counter() - t0) / 2 * 1e3)
+                got = (oi.cpu(), os_.cpu())
+                if ref is None:
+                    ref = got
+                elif not (torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1])):
+                    print("MISMATCH between variants at nq=%d variant %d" % (nq, v))
         gb = rows * dim * 2 / 1e9
-        for v in (0, 1):
+        for v in variants:
             m = statistics.median(res[v])
-            print("%s nq=%4d variant %d: gemm %.2f ms  %.0f GB/s per pass-equivalent  %.0f TFLOP/s" %
-                  (mname, nq, v, m, gb / (m / 1e3), 2.0 * rows * dim * nq / (m / 1e3) / 1e12))
+            print("%s nq=%4d variant %2d: batch %.2f ms  %.0f GB/s row traffic  %.0f TFLOP/s  %.0f QPS" %
+                  (mname, nq, v, m, gb / (m / 1e3), 2.0 * rows * dim * nq / (m / 1e3) / 1e12, nq / (m / 1e3)))
     eng.drop_table(name)
+eng.set_option("gemm16_variant", 0)
 print("fallbacks", eng.stats()[1])

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--no-ceiling", action="store_true")
     args = ap.parse_args()
     dt, esz = {"f32": (_lib.F32, 4), "bf16": (_lib.BF16, 2), "f16": (_lib.F16, 2)}[args.dtype]
     eng = Engine(0)
@@ -37,7 +38,7 @@ def main():
     oc = torch.empty((1,), dtype=torch.int32, device="cuda")
 
     variants = []
-    for nt, (w, bpc), contig in itertools.product((1, 0), ((16, 1), (8, 2), (4, 4), (16, 2), (8, 4)), (0, 1)):
+    for nt, (w, bpc), contig in itertools.product((1, 0), ((16, 1), (8, 2), (4, 4), (16, 2), (8, 4), (8, 3), (8, 6), (8, 8), (4, 8)), (0, 1)):
         variants.append(dict(scan_nt=nt, scan_waves=w, scan_blocks_per_cu=bpc, scan_contiguous=contig))
     results = {i: [] for i in range(len(variants))}
     for rnd in range(args.rounds):
@@ -59,6 +60,8 @@ def main():
     for i in order:
         print("  %-78s %7.0f / %7.0f" % (variants[i], statistics.median(results[i]), max(results[i])))
 
+    if args.no_ceiling:
+        return
     # plain-read ceiling on a separate 8 GiB buffer
     buf = torch.empty(8 << 30, dtype=torch.uint8, device="cuda")
     buf.zero_()

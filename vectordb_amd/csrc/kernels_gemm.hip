@@ -45,6 +45,13 @@ struct GemmParams {
 
 __device__ __forceinline__ f32x4 ldg4(const float* p) { return *(const f32x4*)p; }
 
+// Source of the query operand for k positions past the end of a row.  The operand is switched by
+// ADDRESS, never by masking loaded data: a select on a loaded register makes the wave wait for the
+// load where it is issued, which turns every prefetch into a synchronous load.  A zero query
+// operand is enough (the row operand then re-reads the row's first bytes: finite data times zero).
+__device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};     // never written
+
+template <bool DENSE>
 __global__ void __launch_bounds__(256, 2)
 gemm_thresh_kernel(GemmParams p) {
     __shared__ __attribute__((aligned(16))) float As[GB_M * GB_LD];
@@ -101,8 +108,7 @@ gemm_thresh_kernel(GemmParams p) {
                 const bool ok = c4 < d4;
                 const int c = ok ? c4 * 4 : 0;
                 ra[i] = ldg4(xptr[i] + c);
-                rb[i] = ldg4(qptr[i] + c);
-                if (!ok) { ra[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; rb[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+                rb[i] = ldg4(ok ? qptr[i] + c : (const float*)g_zero16);
             }
         };
         fetch(0);
@@ -154,7 +160,9 @@ gemm_thresh_kernel(GemmParams p) {
                     const long long row = row0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     float key = acc[mi][ni][r];
                     if (p.l2) key = 2.f * key - rn2[mi][r];
-                    if (key > thr[ni] && row < p.n) {
+                    if constexpr (DENSE) {
+                        if (row < p.n && q < p.nq) { p.cand_s[(size_t)q * p.cap + row] = key; p.cand_t[(size_t)q * p.cap + row] = row; }
+                    } else if (key > thr[ni] && row < p.n) {
                         const int pos = atomicAdd(&p.cnt[q], 1);
                         if (pos < p.cap) { p.cand_s[(size_t)q * p.cap + pos] = key; p.cand_t[(size_t)q * p.cap + pos] = row; }
                         else p.lost[q] = 1;
@@ -167,7 +175,7 @@ gemm_thresh_kernel(GemmParams p) {
 
 hipError_t launch_gemm_thresh(const TableView& t, const float* qprep, int nq, int dpad, const float* thr,
                               long long tile0, long long tile_stride, long long ntiles,
-                              float* cand_s, long long* cand_t, int* cnt, int* lost, int cap,
+                              float* cand_s, long long* cand_t, int* cnt, int* lost, int cap, int dense,
                               int n_cu, hipStream_t st) {
     if (ntiles <= 0) return hipSuccess;
     GemmParams p;
@@ -182,7 +190,8 @@ hipError_t launch_gemm_thresh(const TableView& t, const float* qprep, int nq, in
     gx = gx / 8 * 8;
     if (gx < 8) gx = 8;
     if (gx > ntiles) gx = ntiles;
-    hipLaunchKernelGGL(gemm_thresh_kernel, dim3((unsigned)gx, (unsigned)qtiles), dim3(256), 0, st, p);
+    if (dense) hipLaunchKernelGGL(gemm_thresh_kernel<true>, dim3((unsigned)gx, (unsigned)qtiles), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(gemm_thresh_kernel<false>, dim3((unsigned)gx, (unsigned)qtiles), dim3(256), 0, st, p);
     return hipGetLastError();
 }
 
@@ -314,7 +323,7 @@ __device__ __forceinline__ f32x16 mfma16(const u32x4g& a, const u32x4g& b, const
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-template <int DT, bool SPLIT>
+template <int DT, bool SPLIT, int D, bool DENSE>
 __global__ void __launch_bounds__(256, 2)
 gemm16_thresh_kernel(Gemm16Params p) {
     __shared__ __attribute__((aligned(16))) unsigned short As[HB_M * HB_LD];
@@ -346,47 +355,64 @@ gemm16_thresh_kernel(Gemm16Params p) {
         thr[ni] = (q < p.nq) ? p.thr[q] : __builtin_huge_valf();
     }
 
-    for (long long t = blockIdx.x; t < p.ntiles; t += gridDim.x) {
-        const long long row0 = (p.tile0 + t * p.tile_stride) * HB_M;
-        const unsigned short* xptr[4];
+    // The (tile, k-step) pairs of this workgroup form one flat sequence of stages.  A ring of D
+    // stages of operands lives in registers: while stage s is multiplied out of LDS the loads of
+    // stages s+1 .. s+D are in flight, across tile boundaries too.  Every stage issues exactly
+    // one fetch (stages past the end read a zero block), so the number of loads issued after
+    // any given one is the same on every path and the waits before the LDS stores can leave the
+    // younger stages outstanding (loads complete in issue order).
+    const long long my_tiles = (p.ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
+    const long long total = my_tiles * nks;
+    const long long padded = (total + D - 1) / D * D;
+
+    u32x4g ra[D][4], rh[D][4], rl[D][4];
+    long long f_tile = blockIdx.x;          // fetch cursor
+    int f_ks = 0;
+    long long f_left = total;
+    auto fetch = [&](int u) {
+        const bool live = f_left > 0;
+        const long long row0 = (p.tile0 + f_tile * p.tile_stride) * HB_M;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             long long r = row0 + srow[i];
             if (r > p.n - 1) r = p.n - 1;
-            xptr[i] = p.X + (size_t)r * p.ldx;
+            const int c8 = f_ks * (HB_K / 8) + sc8[i];
+            const bool ok = live && c8 < d8;
+            const int c = ok ? c8 * 8 : 0;
+            const unsigned short* xa = live ? p.X + (size_t)r * p.ldx + c : (const unsigned short*)g_zero16;
+            ra[u][i] = __builtin_nontemporal_load((const u32x4g*)xa);                 // rows stream once
+            rh[u][i] = *(const u32x4g*)(ok ? qh[i] + c : (const unsigned short*)g_zero16);
+            if (SPLIT) rl[u][i] = *(const u32x4g*)(ok ? ql[i] + c : (const unsigned short*)g_zero16);
         }
-        f32x16 acc[2][2];
+        --f_left;
+        if (++f_ks == nks) { f_ks = 0; f_tile += gridDim.x; }
+    };
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    for (int u = 0; u < D; ++u) fetch(u);
 
-        u32x4g ra[4], rh[4], rl[4];
-        auto fetch = [&](int ks) {
+    f32x16 acc[2][2];
+    long long c_tile = blockIdx.x;          // compute cursor
+    int c_ks = 0;
+    for (long long s0 = 0; s0 < padded; s0 += D) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int c8 = ks * (HB_K / 8) + sc8[i];
-                const bool ok = c8 < d8;
-                const int c = ok ? c8 * 8 : 0;
-                ra[i] = __builtin_nontemporal_load((const u32x4g*)(xptr[i] + c));     // rows stream once
-                rh[i] = *(const u32x4g*)(qh[i] + c);
-                if (SPLIT) rl[i] = *(const u32x4g*)(ql[i] + c);
-                if (!ok) { ra[i] = (u32x4g){0, 0, 0, 0}; rh[i] = (u32x4g){0, 0, 0, 0}; if (SPLIT) rl[i] = (u32x4g){0, 0, 0, 0}; }
-            }
-        };
-        fetch(0);
-        for (int ks = 0; ks < nks; ++ks) {
+        for (int u = 0; u < D; ++u) {
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                *(u32x4g*)&As[srow[i] * HB_LD + sc8[i] * 8] = ra[i];
-                *(u32x4g*)&Bh[srow[i] * HB_LD + sc8[i] * 8] = rh[i];
-                if (SPLIT) *(u32x4g*)&Bl[srow[i] * HB_LD + sc8[i] * 8] = rl[i];
+                *(u32x4g*)&As[srow[i] * HB_LD + sc8[i] * 8] = ra[u][i];
+                *(u32x4g*)&Bh[srow[i] * HB_LD + sc8[i] * 8] = rh[u][i];
+                if (SPLIT) *(u32x4g*)&Bl[srow[i] * HB_LD + sc8[i] * 8] = rl[u][i];
             }
             __syncthreads();
-            if (ks + 1 < nks) fetch(ks + 1);
+            fetch(u);
+            if (c_ks == 0) {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+            }
 #pragma unroll
             for (int kk = 0; kk < HB_K / 16; ++kk) {
                 u32x4g a8[2], h8[2], l8[2];
@@ -405,31 +431,58 @@ gemm16_thresh_kernel(Gemm16Params p) {
                         if (SPLIT) acc[mi][ni] = mfma16<DT>(a8[mi], l8[ni], acc[mi][ni]);
                     }
             }
-        }
-        float rn2[2][16];
-        if (p.l2) {
+            if (++c_ks == nks) {
+                c_ks = 0;
+                // padded stages beyond the last tile multiply zeros and never reach this point
+                const long long row0 = (p.tile0 + c_tile * p.tile_stride) * HB_M;
+                c_tile += gridDim.x;
+                const long long left = p.n - row0;
+                const int nloc = left < HB_M ? (int)left : HB_M;       // rows of this tile that exist
+                const int q0 = qt * HB_N + wn * 64 + li;
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+                for (int mi = 0; mi < 2; ++mi) {
+                    const int lr0 = wm * 64 + mi * 32 + 4 * lh;         // this lane's rows: lr0 + (r&3) + 8*(r>>2)
+                    float rn2[16];
+                    if (p.l2) {
+                        const float* n2p = p.n2 + row0 + lr0;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const long long row = row0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    rn2[mi][r] = p.n2[row < p.n ? row : p.n - 1];
-                }
-        }
+                        for (int r = 0; r < 16; ++r) {
+                            const int o = (r & 3) + 8 * (r >> 2);
+                            rn2[r] = n2p[lr0 + o < nloc ? o : 0];
+                        }
+                    }
+                    if constexpr (DENSE) {
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int q = qt * HB_N + wn * 64 + ni * 32 + li;
+                        for (int ni = 0; ni < 2; ++ni) {
+                            const int q = q0 + ni * 32;
+                            const size_t base = (size_t)q * p.cap + (size_t)row0;
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
+                            for (int r = 0; r < 16; ++r) {
+                                float key = acc[mi][ni][r];
+                                if (p.l2) key = 2.f * key - rn2[r];
+                                const int lr = lr0 + (r & 3) + 8 * (r >> 2);
+                                if (lr < nloc && q < p.nq) { p.cand_s[base + lr] = key; p.cand_t[base + lr] = row0 + lr; }
+                            }
+                        }
+                        continue;
+                    }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const long long row = row0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    float key = acc[mi][ni][r];
-                    if (p.l2) key = 2.f * key - rn2[mi][r];
-                    if (key > thr[ni] && row < p.n) {
-                        const int pos = atomicAdd(&p.cnt[q], 1);
-                        if (pos < p.cap) { p.cand_s[(size_t)q * p.cap + pos] = key; p.cand_t[(size_t)q * p.cap + pos] = row; }
-                        else p.lost[q] = 1;
+                    for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            float key = acc[mi][ni][r];
+                            if (p.l2) key = 2.f * key - rn2[r];
+                            const int lr = lr0 + (r & 3) + 8 * (r >> 2);
+                            if (__builtin_expect(key > thr[ni] && lr < nloc, 0)) {
+                                // rare: keep every address computation inside this block (an opaque
+                                // copy stops the compiler from hoisting 64 row indices out of it)
+                                int lro = lr, q = q0 + ni * 32;
+                                asm volatile("" : "+v"(lro), "+v"(q));
+                                const int pos = atomicAdd(&p.cnt[q], 1);
+                                if (pos < p.cap) { p.cand_s[(size_t)q * p.cap + pos] = key; p.cand_t[(size_t)q * p.cap + pos] = row0 + lro; }
+                                else p.lost[q] = 1;
+                            }
+                        }
                     }
                 }
             }
@@ -494,8 +547,7 @@ gemm16_stream_kernel(Gemm16Params p) {
                 const int c8 = ks * 8 + kk * 2 + lh;
                 const bool ok = ks < nks && c8 < d8;
                 // plain (cached) loads: four successive loads share each 128-byte line
-                dst[kk] = *(const u32x4g*)(xrow + (ok ? c8 * 8 : 0));
-                if (!ok) dst[kk] = (u32x4g){0, 0, 0, 0};
+                dst[kk] = *(const u32x4g*)(xrow + (ok ? c8 * 8 : 0));        // times a zero query operand
             }
         };
         u32x4g rh[4], rl[4];
@@ -505,9 +557,8 @@ gemm16_stream_kernel(Gemm16Params p) {
                 const int c8 = ks * 8 + sc8[i];
                 const bool ok = c8 < d8;
                 const int c = ok ? c8 * 8 : 0;
-                rh[i] = *(const u32x4g*)(qh[i] + c);
-                if (SPLIT) rl[i] = *(const u32x4g*)(ql[i] + c);
-                if (!ok) { rh[i] = (u32x4g){0, 0, 0, 0}; if (SPLIT) rl[i] = (u32x4g){0, 0, 0, 0}; }
+                rh[i] = *(const u32x4g*)(ok ? qh[i] + c : (const unsigned short*)g_zero16);
+                if (SPLIT) rl[i] = *(const u32x4g*)(ok ? ql[i] + c : (const unsigned short*)g_zero16);
             }
         };
         auto store_b = [&](int buf) {
@@ -583,13 +634,14 @@ gemm16_stream_kernel(Gemm16Params p) {
     }
 }
 
-static int g_gemm16_variant = 0;       // 0 = LDS-staged tile kernel (default: faster up to ~256 queries), 1 = streaming kernel
+// 0 = choose by shape, 1 = streaming kernel, 11 = LDS-staged tile kernel
+static int g_gemm16_variant = 0;
 void set_gemm16_variant(int v) { g_gemm16_variant = v; }
 
 hipError_t launch_gemm16_thresh(const TableView& t, const unsigned short* qhi, const unsigned short* qlo,
                                 int split, int nq, int dpad, const float* thr,
                                 long long tile0, long long tile_stride, long long ntiles,
-                                float* cand_s, long long* cand_t, int* cnt, int* lost, int cap,
+                                float* cand_s, long long* cand_t, int* cnt, int* lost, int cap, int dense,
                                 int n_cu, hipStream_t st) {
     if (ntiles <= 0) return hipSuccess;
     Gemm16Params p;
@@ -598,12 +650,15 @@ hipError_t launch_gemm16_thresh(const TableView& t, const unsigned short* qhi, c
     p.tile0 = tile0; p.tile_stride = tile_stride; p.ntiles = ntiles;
     p.cand_s = cand_s; p.cand_t = cand_t; p.cnt = cnt; p.lost = lost; p.cap = cap;
     const int qtiles = (nq + HB_N - 1) / HB_N;
-    long long gx = (2LL * n_cu) / qtiles;
+    long long gx = (2LL * n_cu) / qtiles;                                       // two workgroups per CU
     gx = gx / 8 * 8;
     if (gx < 8) gx = 8;
     if (gx > ntiles) gx = ntiles;
     const dim3 grid((unsigned)gx, (unsigned)qtiles), block(256);
-    if (g_gemm16_variant == 1) {
+    // measured on 20M x 768: the tile kernel wins with an unsplit query up to two query tiles, the
+    // streaming kernel with more query tiles or a split query (twice the MFMA work per row byte)
+    const bool stream = g_gemm16_variant == 1 || (g_gemm16_variant == 0 && (split || nq > 2 * HB_N));
+    if (stream && !dense) {
         if (t.dt == VDB_BF16) {
             if (split) hipLaunchKernelGGL((gemm16_stream_kernel<VDB_BF16, true>), grid, block, 0, st, p);
             else hipLaunchKernelGGL((gemm16_stream_kernel<VDB_BF16, false>), grid, block, 0, st, p);
@@ -613,13 +668,13 @@ hipError_t launch_gemm16_thresh(const TableView& t, const unsigned short* qhi, c
         }
         return hipGetLastError();
     }
-    if (t.dt == VDB_BF16) {
-        if (split) hipLaunchKernelGGL((gemm16_thresh_kernel<VDB_BF16, true>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((gemm16_thresh_kernel<VDB_BF16, false>), grid, block, 0, st, p);
-    } else {
-        if (split) hipLaunchKernelGGL((gemm16_thresh_kernel<VDB_F16, true>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((gemm16_thresh_kernel<VDB_F16, false>), grid, block, 0, st, p);
-    }
+    // ring depth 1: deeper rings measured no faster (the kernel is bound by LDS and L2 bandwidth,
+    // not by load latency) and cost registers
+#define VDB_G16(DTV, SP) do { if (dense) hipLaunchKernelGGL((gemm16_thresh_kernel<DTV, SP, 1, true>), grid, block, 0, st, p); \
+                               else hipLaunchKernelGGL((gemm16_thresh_kernel<DTV, SP, 1, false>), grid, block, 0, st, p); } while (0)
+    if (t.dt == VDB_BF16) { if (split) VDB_G16(VDB_BF16, true); else VDB_G16(VDB_BF16, false); }
+    else { if (split) VDB_G16(VDB_F16, true); else VDB_G16(VDB_F16, false); }
+#undef VDB_G16
     return hipGetLastError();
 }
 

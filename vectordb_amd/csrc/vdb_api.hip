@@ -332,17 +332,20 @@ static int search_gemm_path(const TableView& tv, const SelGeom& g, int dpad, int
         int* bad = (int*)(thr1 + nqc);
         unsigned short* qhi = (unsigned short*)ws.q16.p;
         unsigned short* qlo = half ? qhi + (size_t)nqc * dpad : nullptr;
-        auto gemm = [&](const TableView& v, const float* thr, long long stride, long long tiles) -> hipError_t {
-            if (half) return launch_gemm16_thresh(v, qhi, qlo, split, nqi, dpad, thr, 0, stride, tiles, cs, ct, cnt, lost, GEMM_CAP, G.n_cu, st);
-            return launch_gemm_thresh(v, qprep, nqi, dpad, thr, 0, stride, tiles, cs, ct, cnt, lost, GEMM_CAP, G.n_cu, st);
+        auto gemm = [&](const TableView& v, const float* thr, long long stride, long long tiles, int dense) -> hipError_t {
+            if (half) return launch_gemm16_thresh(v, qhi, qlo, split, nqi, dpad, thr, 0, stride, tiles, cs, ct, cnt, lost, GEMM_CAP, dense, G.n_cu, st);
+            return launch_gemm_thresh(v, qprep, nqi, dpad, thr, 0, stride, tiles, cs, ct, cnt, lost, GEMM_CAP, dense, G.n_cu, st);
         };
         VDB_HIP(launch_prep_query(q_dev + (size_t)q0 * tv.d, nqi, tv.d, dpad, tv.metric, qprep, qinfo, ne, st));
         VDB_HIP(hipMemsetAsync(bad, 0, (size_t)nqc * 4, st));
         if (half) VDB_HIP(launch_split_query16(tv.dt, qprep, nqi, dpad, qhi, qlo, bad, st));
-        // pass 0: every score of the first n0 (<= GEMM_CAP) rows is kept; thr0 = K-th best of them
-        VDB_HIP(hipMemsetAsync(cnt, 0, (size_t)nqc * 8, st));
+        // pass 0: every score of the first n0 (<= GEMM_CAP) rows is kept, row r in slot r (no
+        // counter traffic: a million atomics on nq addresses cost more than the whole pass);
+        // thr0 = K-th best of them
+        VDB_HIP(hipMemsetD32Async((hipDeviceptr_t)cnt, (int)n0, (size_t)nqc, st));
+        VDB_HIP(hipMemsetAsync(lost, 0, (size_t)nqc * 4, st));
         VDB_HIP(hipMemsetD32Async((hipDeviceptr_t)thr1, (int)0xff800000, (size_t)nqc, st));      // -inf
-        VDB_HIP(gemm(tv0, thr1, 1, (n0 + 127) / 128));
+        VDB_HIP(gemm(tv0, thr1, 1, (n0 + 127) / 128, 1));
         VDB_HIP(launch_kth_threshold(cs, GEMM_CAP, cnt, 0, GEMM_CAP, K, nullptr, thr0, nqi, st));
         float* tau = thr0;
         float* spare = thr1;
@@ -350,7 +353,7 @@ static int search_gemm_path(const TableView& tv, const SelGeom& g, int dpad, int
             // strided sample of `tiles` row tiles under the current threshold -> next threshold
             const long long stride = ntiles / tiles;
             VDB_HIP(hipMemsetAsync(cnt, 0, (size_t)nqc * 8, st));
-            VDB_HIP(gemm(tv, tau, stride, ntiles / stride));
+            VDB_HIP(gemm(tv, tau, stride, ntiles / stride, 0));
             VDB_HIP(launch_kth_threshold(cs, GEMM_CAP, cnt, 0, GEMM_CAP, K, tau, spare, nqi, st));
             std::swap(tau, spare);
         }
@@ -358,7 +361,7 @@ static int search_gemm_path(const TableView& tv, const SelGeom& g, int dpad, int
         VDB_HIP(hipMemsetAsync(cnt, 0, (size_t)nqc * 8, st));
         ProfScope prof;
         if ((rc = prof.begin(st))) return rc;
-        VDB_HIP(gemm(tv, tau, 1, ntiles));
+        VDB_HIP(gemm(tv, tau, 1, ntiles, 0));
         if ((rc = prof.end(st))) return rc;
         VDB_HIP(launch_finalize_flat(tv, qprep, qinfo, nqi, dpad, g, k, cs, ct, cnt, GEMM_CAP, tau, lost, bad, fb,
                                      out_ids + (size_t)q0 * k, out_scores + (size_t)q0 * k, out_counts + q0,

@@ -89,12 +89,12 @@ hipError_t launch_finalize_flat(const TableView& t, const float* qprep, const QI
 // appending every score above thr[q] to query q's candidate array.
 hipError_t launch_gemm_thresh(const TableView& t, const float* qprep, int nq, int dpad, const float* thr,
                               long long tile0, long long tile_stride, long long ntiles,
-                              float* cand_s, long long* cand_t, int* cnt, int* lost, int cap,
+                              float* cand_s, long long* cand_t, int* cnt, int* lost, int cap, int dense,
                               int n_cu, hipStream_t st);
 hipError_t launch_gemm16_thresh(const TableView& t, const unsigned short* qhi, const unsigned short* qlo,
                                 int split, int nq, int dpad, const float* thr,
                                 long long tile0, long long tile_stride, long long ntiles,
-                                float* cand_s, long long* cand_t, int* cnt, int* lost, int cap,
+                                float* cand_s, long long* cand_t, int* cnt, int* lost, int cap, int dense,
                                 int n_cu, hipStream_t st);
 void set_gemm16_variant(int v);
 hipError_t launch_split_query16(int dt, const float* qprep, int nq, int dpad, unsigned short* hi,
