@@ -96,7 +96,8 @@ def main() -> None:
                     help="queries in flight: step i runs on HIP stream i %% streams, as the requests of "
                          "concurrent clients do; the library runs the table scans one after the other and "
                          "overlaps the short kernels and the collective around them")
-    ap.add_argument("--scan-serialize", type=int, default=1, help="0 lets scans of different streams overlap")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
+                    help="library option set through vdb_set_option before the run (A/B runs), e.g. scan_serialize=0")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="0 disables the CPU baseline")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (nccl = RCCL; gloo rehearses the path on fewer GPUs)")
@@ -122,7 +123,9 @@ def main() -> None:
             dist.init_process_group("gloo")
 
     eng = Engine(device=dev_index)
-    eng.set_option("scan_serialize", args.scan_serialize)
+    for kv in args.opt:
+        key, _, val = kv.partition("=")
+        eng.set_option(key, float(val))
     dt, esz = DTYPES[args.dtype]
     metric = METRICS[args.metric]
     first, last = shard_range(args.rows, world, rank)
@@ -217,6 +220,7 @@ def main() -> None:
                 "rows_per_gpu": n_local,
                 "parallelism": "row-shard x%d + RCCL all-gather of top-k records" % world if world > 1 else "single GPU",
                 "streams": n_streams,
+                "options": args.opt,
                 "table_fill_s": round(t_fill, 2),
                 "exact_fallbacks": fallbacks,
                 "queries_counted": queries_done,

@@ -70,7 +70,8 @@ int vdb_shutdown(void);
  * Launch tunables of the scan kernel (defaults are the measured best): "scan_nt",
  * "scan_waves", "scan_blocks_per_cu", "scan_contiguous"; "scan_serialize" (1 = scans issued on
  * different streams run one after the other, chained by events, while the short kernels around
- * them overlap; 0 = scans of different streams may overlap).
+ * them overlap; 0 = scans of different streams may overlap); "scan_sample" (1 = for long candidate
+ * lists over short rows, a scan of 1/256 of the rows first supplies a threshold floor to the full scan).
  * Batched path: "gemm_path" (0 sends every batch through the scan path), "gemm_split_f16"
  * (1 splits fp32 queries into hi + lo halves for fp16 tables as is always done for bf16),
  * "gemm16_variant" (0 = chosen by shape, 1 = register-streaming kernel, 11 = LDS-tiled kernel). */

@@ -473,3 +473,25 @@ def test_queries_in_flight_on_several_streams(engine, table_name, ordered):
     for qi, (wi, ws) in enumerate(want):
         assert np.array_equal(got_ids[qi], wi)
         assert np.array_equal(got_sc[qi].view(np.uint32), ws.view(np.uint32))
+
+
+@pytest.mark.parametrize("metric,dtype,kind", [("ip", "f32", "synth"), ("l2", "bf16", "synth"),
+                                               ("cosine", "f16", "synth"), ("ip", "f32", "ties")])
+def test_sampled_floor_scan_parity(engine, table_name, metric, dtype, kind):
+    """Short rows, long candidate lists (k = 100) and enough rows: the scan starts from a floor taken
+    from a sample of the rows.  Exact results with it, and the same results without it."""
+    n, d, k = 300_000, 64, 100
+    rows = cases.make_rows(kind, 57, n, d)
+    ids = cases.make_ids("hash", 57, n)
+    q = cases.make_queries(kind, 57, 5, d, rows)
+    m = cases.METRICS[metric]
+    stored = _load(engine, table_name, rows, ids, m, cases.DTYPES[dtype])
+    _check(engine, table_name, stored, ids, q, k, m)
+    with_floor = engine.search(table_name, q, k)
+    engine.set_option("scan_sample", 0)
+    try:
+        without = engine.search(table_name, q, k)
+    finally:
+        engine.set_option("scan_sample", 1)
+    for a, b in zip(with_floor, without):
+        assert np.array_equal(a, b)

@@ -14,6 +14,7 @@
 //                always right, used only for flagged queries (massive ties, adversarial data).
 #include "vdb_internal.h"
 #include "select.h"
+#include <cstring>
 
 namespace vdb {
 
@@ -201,6 +202,7 @@ struct ScanParams {
     float*       cand_s;    // [nq][G*W][K]: one sorted list per wave
     long long*   cand_t;
     float*       cand_h;    // [nq][G*W]: best key of each list, contiguous for the finalize kernel
+    const float* floor;     // [nq] lower bound of the K-th best key per query, or null
 };
 
 // Launch tunables of the scan (set through vdb_set_option, defaults chosen by measurement).
@@ -250,7 +252,8 @@ scan_kernel(ScanParams p) {
     }
 
     WaveSel sel;
-    sel.init(S_all + (size_t)wave * p.C, T_all + (size_t)wave * p.C, p.C, p.K, lane);
+    sel.init(S_all + (size_t)wave * p.C, T_all + (size_t)wave * p.C, p.C, p.K, lane,
+             p.floor ? p.floor[blockIdx.y] : neg_inf());
 
     const long long TW = (long long)gridDim.x * W;
     const long long gw = (long long)blockIdx.x * W + wave;
@@ -315,7 +318,8 @@ scan_kernel_generic(ScanParams p) {
     __syncthreads();
 
     WaveSel sel;
-    sel.init(S_all + (size_t)wave * p.C, T_all + (size_t)wave * p.C, p.C, p.K, lane);
+    sel.init(S_all + (size_t)wave * p.C, T_all + (size_t)wave * p.C, p.C, p.K, lane,
+             p.floor ? p.floor[blockIdx.y] : neg_inf());
 
     const long long TW = (long long)gridDim.x * W;
     const long long gw = (long long)blockIdx.x * W + wave;
@@ -427,12 +431,12 @@ static hipError_t launch_scan_dt(const ScanShape& s, dim3 grid, dim3 block, size
 
 hipError_t launch_scan(const TableView& t, const float* qprep, int64_t nq, int dpad,
                        const SelGeom& g, int G, float* cand_s, long long* cand_t, float* cand_h,
-                       hipStream_t st) {
+                       const float* floor, hipStream_t st) {
     ScanParams p;
     p.rows = t.rows; p.n2 = t.n2; p.q = qprep; p.n = t.n; p.m = t.m; p.dpad = dpad;
     p.K = g.K; p.C = g.C; p.l2 = (t.metric == VDB_METRIC_L2) ? 1 : 0;
     p.contiguous = g_tune.contiguous;
-    p.cand_s = cand_s; p.cand_t = cand_t; p.cand_h = cand_h;
+    p.cand_s = cand_s; p.cand_t = cand_t; p.cand_h = cand_h; p.floor = floor;
     const ScanShape s = scan_shape(t.m, t.dt);
     const dim3 grid((unsigned)G, (unsigned)nq), block((unsigned)g.W * 64);
     const size_t lds = (size_t)g.W * g.C * (sizeof(float) + sizeof(long long));
@@ -495,6 +499,7 @@ struct FinParams {
     const int*       flat_lost;  // [nq]
     const int*       flat_bad;   // [nq] query not representable on the batched path (may be null)
     double           dd_mult, extra_rel, extra_abs;   // see FlatBound
+    float*           floor_out;  // lists mode, non-null: only write the K-th best fast key per query and return
 };
 
 __device__ __forceinline__ int pow2_ceil_dev(int v) { int p = 1; while (p < v) p <<= 1; return p; }
@@ -755,6 +760,12 @@ finalize_kernel(FinParams p) {
     }
     __syncthreads();
     STAMP(3);
+    if (!FLAT && p.floor_out) {
+        // threshold-only use: the K-th best key of these lists bounds the K-th best key of any
+        // superset of their rows from below
+        if (tid == 0) p.floor_out[qi] = take_all ? neg_inf() : fkey_inv(thr);
+        return;
+    }
     const int nvalid = take_all ? ctl[4] : K;
     const uint32_t prefix = thr;
 
@@ -848,7 +859,23 @@ hipError_t launch_finalize(const TableView& t, const float* qprep, const QInfo* 
     p.out_ids = out_ids; p.out_scores = out_scores; p.out_counts = out_counts;
     p.need_exact = need_exact; p.counters = counters;
     p.flat_cnt = nullptr; p.flat_cap = 0; p.flat_tau = nullptr; p.flat_lost = nullptr; p.flat_bad = nullptr;
-    p.dd_mult = 1.0; p.extra_rel = 0.0; p.extra_abs = 0.0;
+    p.dd_mult = 1.0; p.extra_rel = 0.0; p.extra_abs = 0.0; p.floor_out = nullptr;
+    int kr = 1; while (kr < g.K) kr <<= 1;
+    const size_t lds = 1088 + (size_t)g.K * 12 + (size_t)kr * 12 + (size_t)FIN_CAP * 8;
+    hipError_t e = allow_lds(finalize_kernel<false>, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((finalize_kernel<false>), dim3((unsigned)nq), dim3(1024), lds, st, p);
+    return hipGetLastError();
+}
+
+// K-th best fast key of G sorted K-lists per query (the scan of a row sample) -> floor_out[q].
+hipError_t launch_lists_floor(const SelGeom& g, int G, int64_t nq, const float* cand_s, const long long* cand_t,
+                              const float* cand_h, float* floor_out, hipStream_t st) {
+    FinParams p;
+    std::memset(&p, 0, sizeof p);
+    p.K = g.K; p.C = g.C; p.G = G; p.k = 1;
+    p.cand_s = cand_s; p.cand_t = cand_t; p.cand_h = cand_h;
+    p.floor_out = floor_out;
     int kr = 1; while (kr < g.K) kr <<= 1;
     const size_t lds = 1088 + (size_t)g.K * 12 + (size_t)kr * 12 + (size_t)FIN_CAP * 8;
     hipError_t e = allow_lds(finalize_kernel<false>, lds);
@@ -870,7 +897,7 @@ hipError_t launch_finalize_flat(const TableView& t, const float* qprep, const QI
     p.out_ids = out_ids; p.out_scores = out_scores; p.out_counts = out_counts;
     p.need_exact = need_exact; p.counters = counters;
     p.flat_cnt = cnt; p.flat_cap = cap; p.flat_tau = tau; p.flat_lost = lost; p.flat_bad = bad;
-    p.dd_mult = fb.dd_mult; p.extra_rel = fb.extra_rel; p.extra_abs = fb.extra_abs;
+    p.dd_mult = fb.dd_mult; p.extra_rel = fb.extra_rel; p.extra_abs = fb.extra_abs; p.floor_out = nullptr;
     int kr = 1; while (kr < g.K) kr <<= 1;
     const size_t lds = 1088 + (size_t)g.K * 12 + (size_t)kr * 12 + (size_t)FIN_CAP * 8;
     hipError_t e = allow_lds(finalize_kernel<true>, lds);

@@ -55,12 +55,16 @@ struct WaveSel {
     int        cnt;       // wave-uniform number of live entries
     float      thr_s;     // a candidate must be better than (thr_s, thr_t)
     long long  thr_t;
+    float      floor_s;   // keys below this are known to be outside the global K best (-inf: unknown)
 
-    __device__ void init(float* s_, long long* t_, int C_, int K_, int lane) {
+    // `floor` is a lower bound of the K-th best key of the whole stream (of all waves): keys below
+    // it are rejected from the first row on; keys equal to it still pass.
+    __device__ void init(float* s_, long long* t_, int C_, int K_, int lane, float floor = neg_inf()) {
         s = s_; t = t_; C = C_; K = K_;
         for (int i = lane; i < C; i += 64) { s[i] = neg_inf(); t[i] = TAG_NONE; }
         cnt = K;                       // K sentinels: any real row beats them
-        thr_s = neg_inf(); thr_t = TAG_NONE;
+        floor_s = floor;
+        thr_s = floor; thr_t = TAG_NONE;
         lds_wave_sync();
     }
 
@@ -73,6 +77,7 @@ struct WaveSel {
         cnt = K;
         thr_s = s[K - 1];
         thr_t = t[K - 1];
+        if (floor_s > thr_s) { thr_s = floor_s; thr_t = TAG_NONE; }
     }
 
     // Called by the whole wave; lanes with pass == true contribute (key, tag).

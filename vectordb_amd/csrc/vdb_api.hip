@@ -78,7 +78,7 @@ struct Global {
     double cache_capacity_gb = 0.0;
     double insert_buffer_gb = 1.0;
     size_t table_bytes = 0;
-    int tune_nt = 1, tune_waves = 8, tune_bpc = 4, tune_contig = 1, tune_gemm = 1, tune_split_f16 = 0;
+    int tune_nt = 1, tune_waves = 8, tune_bpc = 4, tune_contig = 1, tune_gemm = 1, tune_split_f16 = 0, tune_sample = 1;
     // host-insert staging (guarded by insert_mu)
     std::mutex insert_mu;
     DevBuf stage_rows, stage_ids;
@@ -227,6 +227,20 @@ static int search_scan_path(const TableView& tv, const SelGeom& g, int dpad, int
     if ((rc = ensure(ws.cand_t, (size_t)nqc * Gx * g.W * g.K * sizeof(long long), ws.last_stream))) return rc;
     if ((rc = ensure(ws.cand_h, (size_t)nqc * Gx * g.W * sizeof(float), ws.last_stream))) return rc;
     if ((rc = ensure(ws.need_exact, (size_t)(nqc + 1) * sizeof(int), ws.last_stream))) return rc;
+    // Many short rows and a long candidate list: every wave would spend its first K*ln(rows/K)
+    // rows filling and sorting its own list.  A scan of a small sample of the rows (1/256) first
+    // gives the K-th best key of the sample, a lower bound of the K-th best key of the table; the
+    // full scan starts with it as a floor, so that only about 256*K rows in total pass the compare.
+    const size_t rowbytes = (size_t)tv.m * 16;
+    const bool sampled = g.K >= 64 && rowbytes <= 1024 && tv.n >= 262144 && G.tune_sample != 0;
+    TableView tvs = tv;
+    int Gs = 0;
+    if (sampled) {
+        tvs.n = tv.n / 256 > 4LL * g.K ? tv.n / 256 : 4LL * g.K;
+        Gs = scan_grid(tvs, g, G.n_cu);
+        if (Gs > G.n_cu) Gs = G.n_cu;                                 // one block per CU is plenty for 0.4 % of the rows
+        if ((rc = ensure(ws.small, (size_t)nqc * sizeof(float), ws.last_stream))) return rc;
+    }
     for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
         const int64_t nqi = nq - q0 < chunk ? nq - q0 : chunk;
         float* qprep = (float*)ws.qprep.p;
@@ -235,6 +249,12 @@ static int search_scan_path(const TableView& tv, const SelGeom& g, int dpad, int
         long long* ct = (long long*)ws.cand_t.p;
         int* ne = (int*)ws.need_exact.p;
         VDB_HIP(launch_prep_query(q_dev + (size_t)q0 * tv.d, nqi, tv.d, dpad, tv.metric, qprep, qinfo, ne, st));
+        const float* floor = nullptr;
+        if (sampled) {
+            VDB_HIP(launch_scan(tvs, qprep, nqi, dpad, g, Gs, cs, ct, (float*)ws.cand_h.p, nullptr, st));
+            VDB_HIP(launch_lists_floor(g, Gs * g.W, nqi, cs, ct, (const float*)ws.cand_h.p, (float*)ws.small.p, st));
+            floor = (const float*)ws.small.p;
+        }
         {
             // A scan saturates HBM on its own, so scans issued on different streams run one after
             // the other (two at once would only evict each other's cache lines), while the short
@@ -248,7 +268,7 @@ static int search_scan_path(const TableView& tv, const SelGeom& g, int dpad, int
             }
             ProfScope prof;
             if ((rc = prof.begin(st))) return rc;
-            VDB_HIP(launch_scan(tv, qprep, nqi, dpad, g, Gx, cs, ct, (float*)ws.cand_h.p, st));
+            VDB_HIP(launch_scan(tv, qprep, nqi, dpad, g, Gx, cs, ct, (float*)ws.cand_h.p, floor, st));
             if ((rc = prof.end(st))) return rc;
             if (ordered) {
                 const int slot = (G.chain_head + 1) % 16;
@@ -552,6 +572,7 @@ int vdb_set_option(const char* key, double value) {
     else if (k == "scan_blocks_per_cu") { if (value < 0 || value > 32) return fail(VDB_EINVAL, "scan_blocks_per_cu not in [0,32]"); G.tune_bpc = (int)value; }
     else if (k == "scan_contiguous") G.tune_contig = value != 0;
     else if (k == "scan_serialize") { std::lock_guard<std::mutex> cl(G.chain_mu); G.scan_serialize = value != 0; }
+    else if (k == "scan_sample") G.tune_sample = value != 0;
     else if (k == "gemm_path") G.tune_gemm = value != 0;
     else if (k == "gemm_split_f16") G.tune_split_f16 = value != 0;
     else if (k == "gemm16_variant") set_gemm16_variant((int)value);

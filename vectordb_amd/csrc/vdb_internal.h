@@ -61,7 +61,7 @@ hipError_t launch_prep_query(const float* q_raw, int64_t nq, int d, int dpad, in
 int  scan_grid(const TableView& t, const SelGeom& g, int n_cu);
 hipError_t launch_scan(const TableView& t, const float* qprep, int64_t nq, int dpad,
                        const SelGeom& g, int G, float* cand_s, long long* cand_t, float* cand_h,
-                       hipStream_t st);
+                       const float* floor, hipStream_t st);
 
 // Merge candidates, re-score them canonically (fp64), order by (score, id), certify.
 hipError_t launch_finalize(const TableView& t, const float* qprep, const QInfo* qinfo, int64_t nq,
@@ -78,6 +78,8 @@ struct FlatBound {
     double extra_rel = 0.0;   // relative error of the query as the MFMA sees it (x ||x|| ||q||)
     double extra_abs = 0.0;   // absolute error per unit of ||x|| (fp16 subnormal spacing)
 };
+hipError_t launch_lists_floor(const SelGeom& g, int G, int64_t nq, const float* cand_s, const long long* cand_t,
+                              const float* cand_h, float* floor_out, hipStream_t st);
 hipError_t launch_finalize_flat(const TableView& t, const float* qprep, const QInfo* qinfo, int64_t nq,
                                 int dpad, const SelGeom& g, int k,
                                 const float* cand_s, const long long* cand_t, const int* cnt, int cap,
