@@ -266,7 +266,7 @@ def main() -> None:
                 # 16-bit rows: 16x the MFMA rate, so up to a few hundred queries per batch the GEMM
                 # is bound by streaming the rows once per 128-query tile (shared through L2)
                 line["roofline"] = {
-                    "bound": "hbm", "kernel": "gemm16_thresh_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                    "bound": "hbm", "kernel": "gemm16_wide_kernel" if args.nq > 128 else "gemm16_thresh_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                     "bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_scan_s * 1e3,
                     "launches_timed": scan_launches, "mfma_tflops": tf, "mfma_frac_of_2500": tf / 2500.0,

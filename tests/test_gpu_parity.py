@@ -412,12 +412,13 @@ def test_batched_gemm_path_16bit_parity(engine, table_name, metric, dtype, d, nq
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
-@pytest.mark.parametrize("variant", [1, 11])
-def test_both_16bit_gemm_kernels_parity(engine, table_name, variant, dtype):
-    """The library picks one of two 16-bit batched kernels by shape (LDS-staged tile kernel or
-    row fragments streamed straight to registers); forced through the `gemm16_variant` option
-    each must give the same exact results for split (bf16) and unsplit (fp16) queries."""
-    n, d, nq = 70_000, 200, 40
+@pytest.mark.parametrize("variant", [1, 11, 12])
+def test_each_16bit_gemm_kernel_parity(engine, table_name, variant, dtype):
+    """The library picks one of three 16-bit batched kernels by shape (128 x 128 LDS-staged tile
+    kernel, row fragments streamed straight to registers, 256 x 256 wide-tile kernel); forced
+    through the `gemm16_variant` option each must give the same exact results for split (bf16)
+    and unsplit (fp16) queries.  150 queries: more than one 128-query tile, a ragged last tile."""
+    n, d, nq = 70_000, 200, 150
     rows = cases.make_rows("synth", 41, n, d)
     ids = cases.make_ids("hash", 41, n)
     q = cases.make_queries("synth", 41, nq, d, rows)
@@ -429,10 +430,10 @@ def test_both_16bit_gemm_kernels_parity(engine, table_name, variant, dtype):
         engine.set_option("gemm16_variant", 0)
 
 
-def test_wide_batch_takes_the_streaming_kernel(engine, table_name):
-    """More than two query tiles (nq > 256) on an fp16 table: the shape rule selects the streaming
-    kernel; results stay exact."""
-    n, d, nq = 66_000, 64, 300
+def test_wide_batch_default_kernel_choice(engine, table_name):
+    """More than two query tiles (nq > 256) on an fp16 table with the default kernel choice and a
+    row count that is not a multiple of the 256-row tile; results stay exact."""
+    n, d, nq = 66_001, 64, 300
     rows = cases.make_rows("synth", 43, n, d)
     ids = cases.make_ids("index", 43, n)
     q = cases.make_queries("synth", 43, nq, d, rows)

@@ -634,7 +634,185 @@ gemm16_stream_kernel(Gemm16Params p) {
     }
 }
 
-// 0 = choose by shape, 1 = streaming kernel, 11 = LDS-staged tile kernel
+// Wide-tile kernel for more than one query tile.  Measured on the 128 x 128 kernel above: with the
+// 16-bit MFMA rate the bound is not load latency but bytes per flop, of LDS (a 64 x 64 wave tile
+// reads 1 KiB of fragments per MFMA, the LDS peak at full MFMA rate) and of L2 (the query operand
+// is re-read for every 128 rows).  Here a workgroup of 8 waves owns 256 rows x 256 queries and each
+// wave 128 x 64 (128 accumulator registers): 0.75 KiB of fragments per MFMA and half the query
+// traffic per row.  One workgroup per CU, so the LDS tile is double-buffered (one barrier per
+// k-step) and two k-steps of operands ride in registers across tile boundaries.
+constexpr int WB_M = 256, WB_N = 256, WB_K = 32, WB_LD = WB_K + 8;    // LDS row = 40 halfs = 80 bytes
+
+template <int DT, bool SPLIT>
+__global__ void __launch_bounds__(512, 1)
+gemm16_wide_kernel(Gemm16Params p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short wsm[];
+    unsigned short* As = wsm;                                  // [2][WB_M * WB_LD]
+    unsigned short* Bh = As + 2 * WB_M * WB_LD;                // [2][WB_N * WB_LD]
+    unsigned short* Bl = Bh + 2 * WB_N * WB_LD;                // [2][WB_N * WB_LD] (SPLIT only)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int li = lane & 31, lh = lane >> 5;
+    const int qt = blockIdx.y;
+    const int nks = (p.dpad + WB_K - 1) / WB_K;
+    const int d8 = p.dpad >> 3;
+
+    // staging map: 16-byte chunk f = tid + 512 * i, i < 2: tile row f / 4, chunk f % 4 of the k-step
+    int srow[2], sc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const int f = tid + 512 * i; srow[i] = f >> 2; sc[i] = f & 3; }
+    const unsigned short* qh[2];
+    const unsigned short* ql[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int q = qt * WB_N + srow[i];
+        if (q > p.nq - 1) q = p.nq - 1;
+        qh[i] = p.Qhi + (size_t)q * p.dpad;
+        ql[i] = SPLIT ? p.Qlo + (size_t)q * p.dpad : nullptr;
+    }
+    float thr[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int q = qt * WB_N + wn * 64 + ni * 32 + li;
+        thr[ni] = (q < p.nq) ? p.thr[q] : __builtin_huge_valf();
+    }
+
+    // p.ntiles counts 256-row tiles here (tile0 = 0, stride 1: the full pass)
+    const long long my_tiles = (p.ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
+    const long long total = my_tiles * nks;
+    const long long padded = (total + 1) / 2 * 2;
+
+    u32x4g ra[2][2], rh[2][2], rl[2][2];
+    long long f_tile = blockIdx.x;
+    int f_ks = 0;
+    long long f_left = total;
+    auto fetch = [&](int u) {
+        const bool live = f_left > 0;
+        const long long row0 = f_tile * WB_M;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            long long r = row0 + srow[i];
+            if (r > p.n - 1) r = p.n - 1;
+            const int c8 = f_ks * (WB_K / 8) + sc[i];
+            const bool ok = live && c8 < d8;
+            const int c = ok ? c8 * 8 : 0;
+            const unsigned short* xa = live ? p.X + (size_t)r * p.ldx + c : (const unsigned short*)g_zero16;
+            ra[u][i] = __builtin_nontemporal_load((const u32x4g*)xa);
+            rh[u][i] = *(const u32x4g*)(ok ? qh[i] + c : (const unsigned short*)g_zero16);
+            if (SPLIT) rl[u][i] = *(const u32x4g*)(ok ? ql[i] + c : (const unsigned short*)g_zero16);
+        }
+        --f_left;
+        if (++f_ks == nks) { f_ks = 0; f_tile += gridDim.x; }
+    };
+    fetch(0);
+    fetch(1);
+
+    f32x16 acc[4][2];
+    long long c_tile = blockIdx.x;
+    int c_ks = 0;
+    for (long long s0 = 0; s0 < padded; s0 += 2) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            // every wave finished reading buffer u (two k-steps ago) before it passed the last barrier
+            unsigned short* Au = As + u * (WB_M * WB_LD);
+            unsigned short* Hu = Bh + u * (WB_N * WB_LD);
+            unsigned short* Lu = Bl + u * (WB_N * WB_LD);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                *(u32x4g*)&Au[srow[i] * WB_LD + sc[i] * 8] = ra[u][i];
+                *(u32x4g*)&Hu[srow[i] * WB_LD + sc[i] * 8] = rh[u][i];
+                if (SPLIT) *(u32x4g*)&Lu[srow[i] * WB_LD + sc[i] * 8] = rl[u][i];
+            }
+            fetch(u);
+            __syncthreads();
+            if (c_ks == 0) {
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+            }
+#pragma unroll
+            for (int kk = 0; kk < WB_K / 16; ++kk) {
+                u32x4g a8[4], h8[2], l8[2];
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) a8[mi] = *(const u32x4g*)&Au[(wm * 128 + mi * 32 + li) * WB_LD + kk * 16 + lh * 8];
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    h8[ni] = *(const u32x4g*)&Hu[(wn * 64 + ni * 32 + li) * WB_LD + kk * 16 + lh * 8];
+                    if (SPLIT) l8[ni] = *(const u32x4g*)&Lu[(wn * 64 + ni * 32 + li) * WB_LD + kk * 16 + lh * 8];
+                }
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+                        acc[mi][ni] = mfma16<DT>(a8[mi], h8[ni], acc[mi][ni]);
+                        if (SPLIT) acc[mi][ni] = mfma16<DT>(a8[mi], l8[ni], acc[mi][ni]);
+                    }
+            }
+            if (++c_ks == nks) {
+                c_ks = 0;
+                // padded stages beyond the last tile multiply zeros and never reach this point
+                const long long row0 = c_tile * WB_M;
+                c_tile += gridDim.x;
+                const long long left = p.n - row0;
+                const int nloc = left < WB_M ? (int)left : WB_M;
+                const int q0 = qt * WB_N + wn * 64 + li;
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+                    const int lr0 = wm * 128 + mi * 32 + 4 * lh;     // this lane's rows: lr0 + (r&3) + 8*(r>>2)
+                    float rn2[16];
+                    if (p.l2) {
+                        const float* n2p = p.n2 + row0 + lr0;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int o = (r & 3) + 8 * (r >> 2);
+                            rn2[r] = n2p[lr0 + o < nloc ? o : 0];
+                        }
+                    }
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            float key = acc[mi][ni][r];
+                            if (p.l2) key = 2.f * key - rn2[r];
+                            const int lr = lr0 + (r & 3) + 8 * (r >> 2);
+                            if (__builtin_expect(key > thr[ni] && lr < nloc, 0)) {
+                                int lro = lr, q = q0 + ni * 32;
+                                asm volatile("" : "+v"(lro), "+v"(q));
+                                const int pos = atomicAdd(&p.cnt[q], 1);
+                                if (pos < p.cap) { p.cand_s[(size_t)q * p.cap + pos] = key; p.cand_t[(size_t)q * p.cap + pos] = row0 + lro; }
+                                else p.lost[q] = 1;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int DT, bool SPLIT>
+static hipError_t launch_wide(const Gemm16Params& p, int nq, int n_cu, hipStream_t st) {
+    const size_t lds = (size_t)(SPLIT ? 6 : 4) * WB_M * WB_LD * sizeof(unsigned short);
+    static bool allowed = false;
+    if (!allowed) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm16_wide_kernel<DT, SPLIT>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        allowed = true;
+    }
+    const int qtiles = (nq + WB_N - 1) / WB_N;
+    long long gx = (long long)n_cu / qtiles;                  // one workgroup per CU
+    gx = gx / 8 * 8;                                          // query tiles of one row range share an XCD
+    if (gx < 8) gx = 8;
+    if (gx > p.ntiles) gx = p.ntiles;
+    hipLaunchKernelGGL((gemm16_wide_kernel<DT, SPLIT>), dim3((unsigned)gx, (unsigned)qtiles), dim3(512), lds, st, p);
+    return hipGetLastError();
+}
+
+// 0 = choose by shape, 1 = streaming kernel, 11 = LDS-staged tile kernel, 12 = wide-tile kernel
 static int g_gemm16_variant = 0;
 void set_gemm16_variant(int v) { g_gemm16_variant = v; }
 
@@ -657,6 +835,14 @@ hipError_t launch_gemm16_thresh(const TableView& t, const unsigned short* qhi, c
     const dim3 grid((unsigned)gx, (unsigned)qtiles), block(256);
     // measured on 20M x 768: the tile kernel wins with an unsplit query up to two query tiles, the
     // streaming kernel with more query tiles or a split query (twice the MFMA work per row byte)
+    // the wide-tile kernel covers full passes (every row tile) over more than one query tile
+    const bool full = tile0 == 0 && tile_stride == 1 && ntiles == (t.n + HB_M - 1) / HB_M;
+    if (!dense && full && nq > HB_N && (g_gemm16_variant == 0 || g_gemm16_variant == 12)) {
+        Gemm16Params w = p;
+        w.ntiles = (t.n + WB_M - 1) / WB_M;
+        if (t.dt == VDB_BF16) return split ? launch_wide<VDB_BF16, true>(w, nq, n_cu, st) : launch_wide<VDB_BF16, false>(w, nq, n_cu, st);
+        return split ? launch_wide<VDB_F16, true>(w, nq, n_cu, st) : launch_wide<VDB_F16, false>(w, nq, n_cu, st);
+    }
     const bool stream = g_gemm16_variant == 1 || (g_gemm16_variant == 0 && (split || nq > 2 * HB_N));
     if (stream && !dense) {
         if (t.dt == VDB_BF16) {
