@@ -45,7 +45,9 @@ struct Workspace {
     DevBuf small;                                         // batched path: cnt | lost | thr0 | thr1
     DevBuf cand_h;                                        // scan path: list heads
     DevBuf q16;                                           // batched path, 16-bit tables: query hi | lo parts
-    DevBuf q_raw, o_ids, o_scores, o_counts;              // staging of the host entry point
+    DevBuf q_raw, o_ids, o_scores, o_counts;              // staging of the host entry point (o_ids holds ids | scores | counts)
+    void*  h_pin = nullptr;                               // pinned host mirror: queries | ids | scores | counts
+    size_t h_cap = 0;
 };
 
 struct Table {
@@ -534,6 +536,7 @@ int vdb_shutdown(void) {
         for (DevBuf* b : {&w->qprep, &w->qinfo, &w->cand_s, &w->cand_t, &w->need_exact, &w->q_raw,
                           &w->o_ids, &w->o_scores, &w->o_counts, &w->small, &w->cand_h, &w->q16})
             if (b->p) (void)hipFree(b->p);
+        if (w->h_pin) (void)hipHostFree(w->h_pin);
         if (w->stream) (void)hipStreamDestroy(w->stream);
         if (w->done) (void)hipEventDestroy(w->done);
     }
@@ -932,27 +935,52 @@ int vdb_search(const char* name, int64_t nq, const float* queries, int k,
     if ((rc = acquire_ws(nullptr, ws))) return rc;
     hipStream_t st = ws->stream;
     const size_t d = (size_t)t->dim;
+    // Results leave the device as one block (ids | scores | counts) and, like the queries, pass
+    // through a pinned host buffer: copies from and to pageable memory are staged by the runtime
+    // one by one and cost several times the 3 KB they move.
+    const size_t qbytes = (size_t)nq * d * sizeof(float);
+    const size_t ib = (size_t)nq * k * sizeof(long long), sb = (size_t)nq * k * sizeof(float), cb = (size_t)nq * sizeof(int);
+    const size_t obytes = ib + sb + cb;
+    const bool pinned = qbytes + obytes <= ((size_t)64 << 20);
     do {
-        if ((rc = ensure(ws->q_raw, (size_t)nq * d * sizeof(float), ws->last_stream))) break;
-        if ((rc = ensure(ws->o_ids, (size_t)nq * k * sizeof(long long), ws->last_stream))) break;
-        if ((rc = ensure(ws->o_scores, (size_t)nq * k * sizeof(float), ws->last_stream))) break;
-        if ((rc = ensure(ws->o_counts, (size_t)nq * sizeof(int), ws->last_stream))) break;
-        hipError_t e = hipMemcpyAsync(ws->q_raw.p, queries, (size_t)nq * d * sizeof(float), hipMemcpyHostToDevice, st);
+        if ((rc = ensure(ws->q_raw, qbytes, ws->last_stream))) break;
+        if ((rc = ensure(ws->o_ids, obytes, ws->last_stream))) break;
+        char* o_dev = (char*)ws->o_ids.p;
+        if (pinned && ws->h_cap < qbytes + obytes) {
+            if (ws->h_pin) { (void)hipStreamSynchronize(st); (void)hipHostFree(ws->h_pin); ws->h_pin = nullptr; ws->h_cap = 0; }
+            size_t want = (qbytes + obytes) * 2;
+            if (want < 65536) want = 65536;
+            if (hipHostMalloc(&ws->h_pin, want, hipHostMallocDefault) != hipSuccess) { rc = fail(VDB_ENOMEM, "pinned staging buffer"); break; }
+            ws->h_cap = want;
+        }
+        char* hq = pinned ? (char*)ws->h_pin : nullptr;
+        char* ho = pinned ? hq + qbytes : nullptr;
+        if (pinned) std::memcpy(hq, queries, qbytes);
+        hipError_t e = hipMemcpyAsync(ws->q_raw.p, pinned ? (const void*)hq : (const void*)queries, qbytes, hipMemcpyHostToDevice, st);
         if (e != hipSuccess) { rc = fail(VDB_EHIP, std::string("query upload: ") + hipGetErrorString(e)); break; }
         {
             std::shared_lock<std::shared_mutex> tl(t->mu);
             if (t->dropped) rc = fail(VDB_ENOTFOUND, "table was dropped");
-            else rc = search_core(*t, nq, (const float*)ws->q_raw.p, k, (long long*)ws->o_ids.p,
-                                  (float*)ws->o_scores.p, (int*)ws->o_counts.p, st, *ws);
+            else rc = search_core(*t, nq, (const float*)ws->q_raw.p, k, (long long*)o_dev,
+                                  (float*)(o_dev + ib), (int*)(o_dev + ib + sb), st, *ws);
             if (rc == VDB_OK) {
-                e = hipMemcpyAsync(out_ids, ws->o_ids.p, (size_t)nq * k * sizeof(long long), hipMemcpyDeviceToHost, st);
-                if (e == hipSuccess) e = hipMemcpyAsync(out_scores, ws->o_scores.p, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, st);
-                if (e == hipSuccess) e = hipMemcpyAsync(out_counts, ws->o_counts.p, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, st);
+                if (pinned) {
+                    e = hipMemcpyAsync(ho, o_dev, obytes, hipMemcpyDeviceToHost, st);
+                } else {
+                    e = hipMemcpyAsync(out_ids, o_dev, ib, hipMemcpyDeviceToHost, st);
+                    if (e == hipSuccess) e = hipMemcpyAsync(out_scores, o_dev + ib, sb, hipMemcpyDeviceToHost, st);
+                    if (e == hipSuccess) e = hipMemcpyAsync(out_counts, o_dev + ib + sb, cb, hipMemcpyDeviceToHost, st);
+                }
                 if (e == hipSuccess) e = hipStreamSynchronize(st);
                 if (e != hipSuccess) rc = fail(VDB_EHIP, std::string("result download: ") + hipGetErrorString(e));
             } else {
                 (void)hipStreamSynchronize(st);
             }
+        }
+        if (rc == VDB_OK && pinned) {
+            std::memcpy(out_ids, ho, ib);
+            std::memcpy(out_scores, ho + ib, sb);
+            std::memcpy(out_counts, ho + ib + sb, cb);
         }
     } while (0);
     release_ws(ws, st);
