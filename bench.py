@@ -256,7 +256,19 @@ def main() -> None:
             nq_launch = min(args.nq, 1024)
             flops = 2.0 * n_local * args.dim * nq_launch
             tf = flops / avg_scan_s / 1e12 if avg_scan_s > 0 else 0.0
-            if args.dtype == "f32":
+            split32 = args.dtype == "f32" and args.nq >= 64 and "gemm32_split=0" not in args.opt
+            if split32:
+                # fp32 rows on the 16-bit matrix unit: rows and queries as bf16 hi + lo, three products per
+                # term, so the ceiling for algorithmic flops is the dense bf16 peak / 3
+                peak = 2500.0 / 3.0
+                line["dtype"] = "f32 rows; fast pass bf16 hi+lo x3 on MFMA, f32 accumulate; fp64 re-score"
+                line["roofline"] = {
+                    "bound": "mfma", "kernel": "gemm32s_kernel", "achieved": tf, "peak": peak,
+                    "unit": "TFLOP/s", "frac": tf / peak, "traffic": None,
+                    "flops_per_launch": flops, "mfma_flops_per_launch": 3.0 * flops,
+                    "avg_launch_ms": avg_scan_s * 1e3, "launches_timed": scan_launches,
+                }
+            elif args.dtype == "f32":
                 line["roofline"] = {
                     "bound": "mfma", "kernel": "gemm_thresh_kernel", "achieved": tf, "peak": MFMA_F32_PEAK_TF,
                     "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF, "traffic": None,

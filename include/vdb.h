@@ -74,6 +74,8 @@ int vdb_shutdown(void);
  * lists over short rows, a scan of 1/256 of the rows first supplies a threshold floor to the full scan).
  * Batched path: "gemm_path" (0 sends every batch through the scan path), "gemm_split_f16"
  * (1 splits fp32 queries into hi + lo halves for fp16 tables as is always done for bf16),
+ * "gemm32_split" (1 = fp32 tables, 64 queries or more: full pass on the 16-bit MFMA with bf16 hi + lo
+ * operands, three products per term; 0 = fp32 MFMA),
  * "gemm16_variant" (0 = chosen by shape, 1 = register-streaming kernel, 11 = 128x128 LDS-tiled
  * kernel, 12 = 256x256 wide-tile kernel for full passes over more than 128 queries). */
 int vdb_set_option(const char* key, double value);

@@ -496,3 +496,44 @@ def test_sampled_floor_scan_parity(engine, table_name, metric, dtype, kind):
         engine.set_option("scan_sample", 1)
     for a, b in zip(with_floor, without):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("split", [1, 0])
+@pytest.mark.parametrize("metric", ["ip", "cosine", "l2"])
+@pytest.mark.parametrize("d,nq", [(100, 130), (768, 70), (36, 64)])
+def test_batched_fp32_table_both_fast_pass_modes(engine, table_name, metric, d, nq, split):
+    """fp32 tables, 64 queries or more: the full pass runs on the 16-bit matrix unit with bf16 hi + lo
+    operands (`gemm32_split` 1, default) or on the fp32 MFMA (0).  Same exact results either way;
+    dims that are not multiples of 8 exercise the zero padding of the split queries."""
+    n = 70_000
+    rows = cases.make_rows("synth", 61, n, d)
+    ids = cases.make_ids("hash", 61, n)
+    q = cases.make_queries("synth", 61, nq, d, rows)
+    m = cases.METRICS[metric]
+    stored = _load(engine, table_name, rows, ids, m, _lib.F32)
+    engine.set_option("gemm32_split", split)
+    try:
+        before = engine.stats()
+        _check(engine, table_name, stored, ids, q, 10, m)
+        after = engine.stats()
+        assert after[2] - before[2] == nq           # took the batched path
+    finally:
+        engine.set_option("gemm32_split", 1)
+
+
+def test_batched_fp32_split_with_large_magnitudes_and_ties(engine, table_name):
+    """Rows with a wide range of magnitudes and quantised duplicates: the bf16 hi + lo fast pass may
+    fail its certificate, never its result."""
+    n, d, nq = 70_000, 64, 80
+    rows = cases.make_rows("ties", 63, n, d)
+    rows[::7] *= 1000.0
+    rows[1::11] *= 1e-4
+    ids = cases.make_ids("negdesc", 63, n)
+    q = cases.make_queries("ties", 63, nq, d, rows)
+    for metric in (O.IP, O.L2):
+        name = table_name + "_%d" % metric
+        stored = _load(engine, name, rows, ids, metric, _lib.F32)
+        try:
+            _check(engine, name, stored, ids, q, 10, metric)
+        finally:
+            engine.drop_table(name)

@@ -812,6 +812,234 @@ static hipError_t launch_wide(const Gemm16Params& p, int nq, int n_cu, hipStream
     return hipGetLastError();
 }
 
+// fp32 tables on the 16-bit matrix unit.  The fast pass only has to be accurate to the bound the
+// certificate uses, so a row value x is presented as bf16 hi + lo (hi = rne(x), lo = rne(x - hi),
+// converted in registers on the way to LDS) and the query likewise; three products are accumulated,
+// xh*qh + xh*ql + xl*qh, leaving a relative error of 3 * 2^-16 per term against 16 x the fp32 MFMA
+// rate / 3.  A workgroup of 8 waves owns 256 rows x 128 queries (64 x 64 per wave), LDS tiles are
+// double-buffered, two k-steps of operands ride in registers across tile boundaries.
+constexpr int SB_M = 256, SB_N = 128, SB_K = 32, SB_LD = SB_K + 8;     // LDS row = 40 halfs = 80 bytes
+typedef __bf16 bf16x2g __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2g __attribute__((ext_vector_type(2)));
+
+struct Gemm32sParams {
+    const float* X;              // [n][ldx] fp32 rows
+    const float* n2;
+    const unsigned short* Qhi;   // [nq][qstride] bf16, zero padded to a multiple of 8
+    const unsigned short* Qlo;
+    const float* thr;
+    long long    n;
+    int          nq;
+    int          dpad;           // floats per row (multiple of 4)
+    int          qstride;        // halfs per query row (multiple of 8)
+    int          ldx;
+    int          l2;
+    long long    ntiles;         // 256-row tiles
+    float*       cand_s;
+    long long*   cand_t;
+    int*         cnt;
+    int*         lost;
+    int          cap;
+};
+
+// 4 fp32 -> 4 bf16 hi (packed in 8 bytes) and 4 bf16 lo
+__device__ __forceinline__ void split4_bf16(const f32x4& x, u32x2g& hi, u32x2g& lo) {
+    unsigned short h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const __bf16 hb = (__bf16)x[e];
+        const float r = x[e] - (float)hb;
+        const __bf16 lb = (__bf16)r;
+        h[e] = __builtin_bit_cast(unsigned short, hb);
+        l[e] = __builtin_bit_cast(unsigned short, lb);
+    }
+    hi[0] = (unsigned int)h[0] | ((unsigned int)h[1] << 16); hi[1] = (unsigned int)h[2] | ((unsigned int)h[3] << 16);
+    lo[0] = (unsigned int)l[0] | ((unsigned int)l[1] << 16); lo[1] = (unsigned int)l[2] | ((unsigned int)l[3] << 16);
+}
+
+__global__ void __launch_bounds__(512, 1)
+gemm32s_kernel(Gemm32sParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short ssm[];
+    unsigned short* Ah = ssm;                                  // [2][SB_M * SB_LD]
+    unsigned short* Al = Ah + 2 * SB_M * SB_LD;
+    unsigned short* Bh = Al + 2 * SB_M * SB_LD;                // [2][SB_N * SB_LD]
+    unsigned short* Bl = Bh + 2 * SB_N * SB_LD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int qt = blockIdx.y;
+    const int nks = (p.dpad + SB_K - 1) / SB_K;
+    const int d4 = p.dpad >> 2;                    // 4-float chunks per row
+    const int q8 = p.qstride >> 3;                 // 8-half chunks per query row
+
+    // staging: row chunks f = tid + 512 * i (i < 4): tile row f / 8, 4-float chunk f % 8;
+    //          query chunk tid: tile query tid / 4, 8-half chunk tid % 4
+    int arow[4], ac[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int f = tid + 512 * i; arow[i] = f >> 3; ac[i] = f & 7; }
+    const int brow = tid >> 2, bc = tid & 3;
+    int qb = qt * SB_N + brow;
+    if (qb > p.nq - 1) qb = p.nq - 1;
+    const unsigned short* qh = p.Qhi + (size_t)qb * p.qstride;
+    const unsigned short* ql = p.Qlo + (size_t)qb * p.qstride;
+    float thr[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int q = qt * SB_N + wn * 64 + ni * 32 + li;
+        thr[ni] = (q < p.nq) ? p.thr[q] : __builtin_huge_valf();
+    }
+
+    const long long my_tiles = (p.ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
+    const long long total = my_tiles * nks;
+    const long long padded = (total + 1) / 2 * 2;
+
+    f32x4 ra[2][4];
+    u32x4g rh[2], rl[2];
+    long long f_tile = blockIdx.x;
+    int f_ks = 0;
+    long long f_left = total;
+    auto fetch = [&](int u) {
+        const bool live = f_left > 0;
+        const long long row0 = f_tile * SB_M;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            long long r = row0 + arow[i];
+            if (r > p.n - 1) r = p.n - 1;
+            const int c4 = f_ks * (SB_K / 4) + ac[i];
+            // past the row's end the row operand re-reads the row's first bytes: the query operand is zero there
+            const float* xa = live ? p.X + (size_t)r * p.ldx + (c4 < d4 ? c4 * 4 : 0) : (const float*)g_zero16;
+            ra[u][i] = __builtin_nontemporal_load((const f32x4*)xa);
+        }
+        const int c8 = f_ks * (SB_K / 8) + bc;
+        const bool okq = live && c8 < q8;
+        rh[u] = *(const u32x4g*)(okq ? qh + c8 * 8 : (const unsigned short*)g_zero16);
+        rl[u] = *(const u32x4g*)(okq ? ql + c8 * 8 : (const unsigned short*)g_zero16);
+        --f_left;
+        if (++f_ks == nks) { f_ks = 0; f_tile += gridDim.x; }
+    };
+    fetch(0);
+    fetch(1);
+
+    f32x16 acc[2][2];
+    long long c_tile = blockIdx.x;
+    int c_ks = 0;
+    for (long long s0 = 0; s0 < padded; s0 += 2) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            // every wave finished reading buffer u (two k-steps ago) before it passed the last barrier
+            unsigned short* Ahu = Ah + u * (SB_M * SB_LD);
+            unsigned short* Alu = Al + u * (SB_M * SB_LD);
+            unsigned short* Bhu = Bh + u * (SB_N * SB_LD);
+            unsigned short* Blu = Bl + u * (SB_N * SB_LD);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                u32x2g h2, l2;
+                split4_bf16(ra[u][i], h2, l2);
+                *(u32x2g*)&Ahu[arow[i] * SB_LD + ac[i] * 4] = h2;
+                *(u32x2g*)&Alu[arow[i] * SB_LD + ac[i] * 4] = l2;
+            }
+            *(u32x4g*)&Bhu[brow * SB_LD + bc * 8] = rh[u];
+            *(u32x4g*)&Blu[brow * SB_LD + bc * 8] = rl[u];
+            fetch(u);
+            __syncthreads();
+            if (c_ks == 0) {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+            }
+#pragma unroll
+            for (int kk = 0; kk < SB_K / 16; ++kk) {
+                u32x4g ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    ah[mi] = *(const u32x4g*)&Ahu[(wm * 64 + mi * 32 + li) * SB_LD + kk * 16 + lh * 8];
+                    al[mi] = *(const u32x4g*)&Alu[(wm * 64 + mi * 32 + li) * SB_LD + kk * 16 + lh * 8];
+                }
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    bh[ni] = *(const u32x4g*)&Bhu[(wn * 64 + ni * 32 + li) * SB_LD + kk * 16 + lh * 8];
+                    bl[ni] = *(const u32x4g*)&Blu[(wn * 64 + ni * 32 + li) * SB_LD + kk * 16 + lh * 8];
+                }
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+                        acc[mi][ni] = mfma16<VDB_BF16>(al[mi], bh[ni], acc[mi][ni]);
+                        acc[mi][ni] = mfma16<VDB_BF16>(ah[mi], bl[ni], acc[mi][ni]);
+                        acc[mi][ni] = mfma16<VDB_BF16>(ah[mi], bh[ni], acc[mi][ni]);
+                    }
+            }
+            if (++c_ks == nks) {
+                c_ks = 0;
+                // padded stages beyond the last tile multiply zeros and never reach this point
+                const long long row0 = c_tile * SB_M;
+                c_tile += gridDim.x;
+                const long long left = p.n - row0;
+                const int nloc = left < SB_M ? (int)left : SB_M;
+                const int q0 = qt * SB_N + wn * 64 + li;
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    const int lr0 = wm * 64 + mi * 32 + 4 * lh;       // this lane's rows: lr0 + (r&3) + 8*(r>>2)
+                    float rn2[16];
+                    if (p.l2) {
+                        const float* n2p = p.n2 + row0 + lr0;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int o = (r & 3) + 8 * (r >> 2);
+                            rn2[r] = n2p[lr0 + o < nloc ? o : 0];
+                        }
+                    }
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            float key = acc[mi][ni][r];
+                            if (p.l2) key = 2.f * key - rn2[r];
+                            const int lr = lr0 + (r & 3) + 8 * (r >> 2);
+                            if (__builtin_expect(key > thr[ni] && lr < nloc, 0)) {
+                                int lro = lr, q = q0 + ni * 32;
+                                asm volatile("" : "+v"(lro), "+v"(q));
+                                const int pos = atomicAdd(&p.cnt[q], 1);
+                                if (pos < p.cap) { p.cand_s[(size_t)q * p.cap + pos] = key; p.cand_t[(size_t)q * p.cap + pos] = row0 + lro; }
+                                else p.lost[q] = 1;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Full pass over an fp32 table with the kernel above; qhi/qlo from launch_split_query16 (bf16,
+// stride qstride).
+hipError_t launch_gemm32s(const TableView& t, const unsigned short* qhi, const unsigned short* qlo, int qstride,
+                          int nq, int dpad, const float* thr, float* cand_s, long long* cand_t,
+                          int* cnt, int* lost, int cap, int n_cu, hipStream_t st) {
+    Gemm32sParams p;
+    p.X = (const float*)t.rows; p.n2 = t.n2; p.Qhi = qhi; p.Qlo = qlo; p.thr = thr; p.n = t.n; p.nq = nq;
+    p.dpad = dpad; p.qstride = qstride; p.ldx = t.m * 4; p.l2 = t.metric == VDB_METRIC_L2 ? 1 : 0;
+    p.ntiles = (t.n + SB_M - 1) / SB_M;
+    p.cand_s = cand_s; p.cand_t = cand_t; p.cnt = cnt; p.lost = lost; p.cap = cap;
+    const size_t lds = (size_t)2 * (2 * SB_M + 2 * SB_N) * SB_LD * sizeof(unsigned short);
+    static bool allowed = false;
+    if (!allowed) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm32s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        allowed = true;
+    }
+    const int qtiles = (nq + SB_N - 1) / SB_N;
+    long long gx = (long long)n_cu / qtiles;                  // one workgroup per CU
+    gx = gx / 8 * 8;                                          // query tiles of one row range share an XCD
+    if (gx < 8) gx = 8;
+    if (gx > p.ntiles) gx = p.ntiles;
+    hipLaunchKernelGGL(gemm32s_kernel, dim3((unsigned)gx, (unsigned)qtiles), dim3(512), lds, st, p);
+    return hipGetLastError();
+}
+
 // 0 = choose by shape, 1 = streaming kernel, 11 = LDS-staged tile kernel, 12 = wide-tile kernel
 static int g_gemm16_variant = 0;
 void set_gemm16_variant(int v) { g_gemm16_variant = v; }
@@ -868,12 +1096,13 @@ hipError_t launch_gemm16_thresh(const TableView& t, const unsigned short* qhi, c
 // finite (fp16 overflow) is flagged as lost so that the exact pass answers it.
 template <int DT>
 __global__ void __launch_bounds__(256)
-split_query16_kernel(const float* __restrict__ q, int dpad, unsigned short* __restrict__ hi,
+split_query16_kernel(const float* __restrict__ q, int dpad, int stride_out, unsigned short* __restrict__ hi,
                      unsigned short* __restrict__ lo, int* __restrict__ lost) {
     const size_t base = (size_t)blockIdx.x * dpad;
+    const size_t obase = (size_t)blockIdx.x * stride_out;
     bool bad = false;
-    for (int j = threadIdx.x; j < dpad; j += blockDim.x) {
-        const float x = q[base + j];
+    for (int j = threadIdx.x; j < stride_out; j += blockDim.x) {
+        const float x = j < dpad ? q[base + j] : 0.f;          // zero padding up to the output stride
         unsigned short h, l;
         float hf;
         if constexpr (DT == VDB_BF16) {
@@ -890,16 +1119,16 @@ split_query16_kernel(const float* __restrict__ q, int dpad, unsigned short* __re
             __builtin_memcpy(&l, &ll, 2);
         }
         if (!(fabsf(hf) <= 3.0e38f)) bad = true;
-        hi[base + j] = h;
-        lo[base + j] = l;
+        hi[obase + j] = h;
+        lo[obase + j] = l;
     }
     if (bad) lost[blockIdx.x] = 1;
 }
 
-hipError_t launch_split_query16(int dt, const float* qprep, int nq, int dpad, unsigned short* hi,
+hipError_t launch_split_query16(int dt, const float* qprep, int nq, int dpad, int stride_out, unsigned short* hi,
                                 unsigned short* lo, int* lost, hipStream_t st) {
-    if (dt == VDB_BF16) hipLaunchKernelGGL((split_query16_kernel<VDB_BF16>), dim3((unsigned)nq), dim3(256), 0, st, qprep, dpad, hi, lo, lost);
-    else hipLaunchKernelGGL((split_query16_kernel<VDB_F16>), dim3((unsigned)nq), dim3(256), 0, st, qprep, dpad, hi, lo, lost);
+    if (dt == VDB_BF16) hipLaunchKernelGGL((split_query16_kernel<VDB_BF16>), dim3((unsigned)nq), dim3(256), 0, st, qprep, dpad, stride_out, hi, lo, lost);
+    else hipLaunchKernelGGL((split_query16_kernel<VDB_F16>), dim3((unsigned)nq), dim3(256), 0, st, qprep, dpad, stride_out, hi, lo, lost);
     return hipGetLastError();
 }
 

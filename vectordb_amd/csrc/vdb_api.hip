@@ -80,7 +80,7 @@ struct Global {
     double cache_capacity_gb = 0.0;
     double insert_buffer_gb = 1.0;
     size_t table_bytes = 0;
-    int tune_nt = 1, tune_waves = 8, tune_bpc = 4, tune_contig = 1, tune_gemm = 1, tune_split_f16 = 0, tune_sample = 1;
+    int tune_nt = 1, tune_waves = 8, tune_bpc = 4, tune_contig = 1, tune_gemm = 1, tune_split_f16 = 0, tune_sample = 1, tune_gemm32s = 1;
     // host-insert staging (guarded by insert_mu)
     std::mutex insert_mu;
     DevBuf stage_rows, stage_ids;
@@ -328,9 +328,13 @@ static int search_gemm_path(const TableView& tv, const SelGeom& g, int dpad, int
     // bf16 carries 8 significant bits: always use both parts; fp16 carries 11: the hi part alone
     // leaves a relative query error of 2^-11, which the certificate accounts for
     const int split = tv.dt == VDB_BF16 ? 1 : (G.tune_split_f16 ? 1 : 0);
+    // fp32 tables: the full pass runs on the 16-bit matrix unit with rows and queries presented as
+    // bf16 hi + lo and three products per term (relative error 3 * 2^-16 per term, in the bound below)
+    const bool s32 = !half && G.tune_gemm32s != 0 && nq >= 64;
+    const int qstride = (dpad + 7) / 8 * 8;
     FlatBound fb;
-    fb.dd_mult = (half && split) ? 2.0 : 1.0;
-    fb.extra_rel = !half ? 0.0 : (tv.dt == VDB_BF16 ? 1.6e-5 : (split ? 2.5e-7 : 4.9e-4));
+    fb.dd_mult = s32 ? 3.0 : ((half && split) ? 2.0 : 1.0);
+    fb.extra_rel = s32 ? 5.0e-5 : (!half ? 0.0 : (tv.dt == VDB_BF16 ? 1.6e-5 : (split ? 2.5e-7 : 4.9e-4)));
     fb.extra_abs = tv.dt == VDB_F16 ? 3.0e-8 * std::sqrt((double)tv.d) : 0.0;      // fp16 subnormal steps
     int rc;
     if ((rc = ensure(ws.qprep, (size_t)nqc * dpad * sizeof(float), ws.last_stream))) return rc;
@@ -339,7 +343,7 @@ static int search_gemm_path(const TableView& tv, const SelGeom& g, int dpad, int
     if ((rc = ensure(ws.cand_t, slots * sizeof(long long), ws.last_stream))) return rc;
     if ((rc = ensure(ws.need_exact, (size_t)(nqc + 1) * sizeof(int), ws.last_stream))) return rc;
     if ((rc = ensure(ws.small, (size_t)nqc * 20, ws.last_stream))) return rc;
-    if (half && (rc = ensure(ws.q16, (size_t)nqc * dpad * 4, ws.last_stream))) return rc;
+    if ((half || s32) && (rc = ensure(ws.q16, (size_t)nqc * qstride * 4, ws.last_stream))) return rc;
     for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
         const int nqi = (int)(nq - q0 < chunk ? nq - q0 : chunk);
         float* qprep = (float*)ws.qprep.p;
@@ -353,14 +357,15 @@ static int search_gemm_path(const TableView& tv, const SelGeom& g, int dpad, int
         float* thr1 = thr0 + nqc;
         int* bad = (int*)(thr1 + nqc);
         unsigned short* qhi = (unsigned short*)ws.q16.p;
-        unsigned short* qlo = half ? qhi + (size_t)nqc * dpad : nullptr;
+        unsigned short* qlo = (half || s32) ? qhi + (size_t)nqc * qstride : nullptr;
         auto gemm = [&](const TableView& v, const float* thr, long long stride, long long tiles, int dense) -> hipError_t {
             if (half) return launch_gemm16_thresh(v, qhi, qlo, split, nqi, dpad, thr, 0, stride, tiles, cs, ct, cnt, lost, GEMM_CAP, dense, G.n_cu, st);
             return launch_gemm_thresh(v, qprep, nqi, dpad, thr, 0, stride, tiles, cs, ct, cnt, lost, GEMM_CAP, dense, G.n_cu, st);
         };
         VDB_HIP(launch_prep_query(q_dev + (size_t)q0 * tv.d, nqi, tv.d, dpad, tv.metric, qprep, qinfo, ne, st));
         VDB_HIP(hipMemsetAsync(bad, 0, (size_t)nqc * 4, st));
-        if (half) VDB_HIP(launch_split_query16(tv.dt, qprep, nqi, dpad, qhi, qlo, bad, st));
+        if (half) VDB_HIP(launch_split_query16(tv.dt, qprep, nqi, dpad, dpad, qhi, qlo, bad, st));
+        if (s32) VDB_HIP(launch_split_query16(VDB_BF16, qprep, nqi, dpad, qstride, qhi, qlo, bad, st));
         // pass 0: every score of the first n0 (<= GEMM_CAP) rows is kept, row r in slot r (no
         // counter traffic: a million atomics on nq addresses cost more than the whole pass);
         // thr0 = K-th best of them
@@ -383,7 +388,8 @@ static int search_gemm_path(const TableView& tv, const SelGeom& g, int dpad, int
         VDB_HIP(hipMemsetAsync(cnt, 0, (size_t)nqc * 8, st));
         ProfScope prof;
         if ((rc = prof.begin(st))) return rc;
-        VDB_HIP(gemm(tv, tau, 1, ntiles, 0));
+        if (s32) VDB_HIP(launch_gemm32s(tv, qhi, qlo, qstride, nqi, dpad, tau, cs, ct, cnt, lost, GEMM_CAP, G.n_cu, st));
+        else VDB_HIP(gemm(tv, tau, 1, ntiles, 0));
         if ((rc = prof.end(st))) return rc;
         VDB_HIP(launch_finalize_flat(tv, qprep, qinfo, nqi, dpad, g, k, cs, ct, cnt, GEMM_CAP, tau, lost, bad, fb,
                                      out_ids + (size_t)q0 * k, out_scores + (size_t)q0 * k, out_counts + q0,
@@ -578,6 +584,7 @@ int vdb_set_option(const char* key, double value) {
     else if (k == "scan_sample") G.tune_sample = value != 0;
     else if (k == "gemm_path") G.tune_gemm = value != 0;
     else if (k == "gemm_split_f16") G.tune_split_f16 = value != 0;
+    else if (k == "gemm32_split") G.tune_gemm32s = value != 0;
     else if (k == "gemm16_variant") set_gemm16_variant((int)value);
     else return fail(VDB_EINVAL, "unknown option: " + k);
     set_scan_tune(G.tune_nt, G.tune_waves, G.tune_bpc, G.tune_contig);

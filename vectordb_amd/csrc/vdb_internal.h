@@ -99,7 +99,10 @@ hipError_t launch_gemm16_thresh(const TableView& t, const unsigned short* qhi, c
                                 float* cand_s, long long* cand_t, int* cnt, int* lost, int cap, int dense,
                                 int n_cu, hipStream_t st);
 void set_gemm16_variant(int v);
-hipError_t launch_split_query16(int dt, const float* qprep, int nq, int dpad, unsigned short* hi,
+hipError_t launch_gemm32s(const TableView& t, const unsigned short* qhi, const unsigned short* qlo, int qstride,
+                          int nq, int dpad, const float* thr, float* cand_s, long long* cand_t,
+                          int* cnt, int* lost, int cap, int n_cu, hipStream_t st);
+hipError_t launch_split_query16(int dt, const float* qprep, int nq, int dpad, int stride_out, unsigned short* hi,
                                 unsigned short* lo, int* bad, hipStream_t st);
 // thr_out[q] = max(thr_in[q], K-th best key among query q's candidates); candidates of query q start
 // at cand_s + q*stride and number cnt[q] (capped at cap), or count_all when cnt is null.
