@@ -290,9 +290,11 @@ static int search_scan_path(const TableView& tv, const SelGeom& g, int dpad, int
     return VDB_OK;
 }
 
-// Batched path: MFMA GEMM with a thresholded epilogue (fp32 MFMA for fp32 tables, 16-bit MFMA
-// with the query split into hi + lo parts for bf16 / fp16 tables), thresholds bootstrapped by two
-// smaller passes (all scores of the first rows, then a strided sample of the row tiles).
+// Batched path: MFMA GEMM with a thresholded epilogue.  Thresholds are bootstrapped by smaller
+// passes (all scores of the first rows, then strided samples of the row tiles, each larger than
+// the last); the full pass runs on the 16-bit MFMA for every table type: bf16 / fp16 rows with the
+// query split into hi + lo parts, fp32 rows split into bf16 hi + lo as well (from 64 queries; the
+// fp32 MFMA kernel serves smaller batches and the sampled passes).
 static int search_gemm_path(const TableView& tv, const SelGeom& g, int dpad, int64_t nq, const float* q_dev,
                             int k, long long* out_ids, float* out_scores, int* out_counts,
                             hipStream_t st, Workspace& ws) {
