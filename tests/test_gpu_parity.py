@@ -335,9 +335,15 @@ def test_one_million_rows_properties(engine, table_name):
         ssc = O.scores(sample, qp, O.COSINE)
         better = np.nonzero(ssc > sc[qi, k - 1])[0] + sample0
         assert set(better.tolist()) <= set(ids[qi].tolist())
-    # idempotence
+    # idempotence, and the per-query scan path gives the same answer as the batched path
     ids2, sc2, _ = engine.search(table_name, q, k)
     assert np.array_equal(ids, ids2) and np.array_equal(sc.view(np.uint32), sc2.view(np.uint32))
+    engine.set_option("gemm_path", 0)
+    try:
+        ids3, sc3, _ = engine.search(table_name, q, k)
+    finally:
+        engine.set_option("gemm_path", 1)
+    assert np.array_equal(ids, ids3) and np.array_equal(sc.view(np.uint32), sc3.view(np.uint32))
     assert engine.stats()[1] >= 0
 
 
@@ -345,7 +351,7 @@ def test_one_million_rows_properties(engine, table_name):
 @pytest.mark.parametrize("metric", ["ip", "cosine", "l2"])
 @pytest.mark.parametrize("d,nq", [(96, 33), (100, 130), (768, 24)])
 def test_batched_gemm_path_parity(engine, table_name, metric, d, nq):
-    """Batches of at least engine_config.use_blas_threshold (20) queries on an fp32 table of at
+    """Batches of at least engine_config.use_blas_threshold queries on an fp32 table of at
     least 65536 rows run the MFMA GEMM with the thresholded epilogue; same bar as the scan path."""
     n = 70_000
     rows = cases.make_rows("synth", 900 + d, n, d)
@@ -487,13 +493,15 @@ def test_sampled_floor_scan_parity(engine, table_name, metric, dtype, kind):
     q = cases.make_queries(kind, 57, 5, d, rows)
     m = cases.METRICS[metric]
     stored = _load(engine, table_name, rows, ids, m, cases.DTYPES[dtype])
-    _check(engine, table_name, stored, ids, q, k, m)
-    with_floor = engine.search(table_name, q, k)
-    engine.set_option("scan_sample", 0)
+    engine.set_option("gemm_path", 0)           # five queries would otherwise go to the batched path
     try:
+        _check(engine, table_name, stored, ids, q, k, m)
+        with_floor = engine.search(table_name, q, k)
+        engine.set_option("scan_sample", 0)
         without = engine.search(table_name, q, k)
     finally:
         engine.set_option("scan_sample", 1)
+        engine.set_option("gemm_path", 1)
     for a, b in zip(with_floor, without):
         assert np.array_equal(a, b)
 

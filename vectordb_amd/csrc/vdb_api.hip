@@ -76,7 +76,7 @@ struct Global {
     std::vector<std::unique_ptr<Workspace>> free_ws;
     long long* d_counters = nullptr;
     // options
-    int use_blas_threshold = 20;
+    int use_blas_threshold = 3;          // measured crossover: one GEMM pass costs about two scans
     double cache_capacity_gb = 0.0;
     double insert_buffer_gb = 1.0;
     size_t table_bytes = 0;
@@ -332,7 +332,7 @@ static int search_gemm_path(const TableView& tv, const SelGeom& g, int dpad, int
     const int split = tv.dt == VDB_BF16 ? 1 : (G.tune_split_f16 ? 1 : 0);
     // fp32 tables: the full pass runs on the 16-bit matrix unit with rows and queries presented as
     // bf16 hi + lo and three products per term (relative error 3 * 2^-16 per term, in the bound below)
-    const bool s32 = !half && G.tune_gemm32s != 0 && nq >= 64;
+    const bool s32 = !half && G.tune_gemm32s != 0;
     const int qstride = (dpad + 7) / 8 * 8;
     FlatBound fb;
     fb.dd_mult = s32 ? 3.0 : ((half && split) ? 2.0 : 1.0);
