@@ -419,8 +419,16 @@ static int search_core(Table& t, int64_t nq, const float* q_dev, int k, long lon
     SelGeom g = sel_geom(k);
     if (G.tune_waves > 0 && G.tune_waves < g.W) g.W = G.tune_waves;
     // engine_config.use_blas_threshold: batches at least this large take the GEMM path
-    const bool gemm = nq >= G.use_blas_threshold && tv.n >= 65536 && g.K <= 256 &&
-                      G.tune_gemm != 0;
+    bool gemm = nq >= G.use_blas_threshold && tv.n >= 65536 && g.K <= 256 && G.tune_gemm != 0;
+    if (gemm) {
+        // Small tables: a batched pass has a fixed cost (threshold passes, flat finalize) that a
+        // few scans undercut.  Both estimates are fits of measured times (seconds; row bytes B).
+        const double B = (double)tv.n * tv.m * 16.0;
+        const double pass_rate = tv.dt == VDB_F32 ? 3.8e12 : (tv.dt == VDB_BF16 || G.tune_split_f16 ? 2.3e12 : 4.0e12);
+        const double est_scan = 60e-6 + (double)nq * (20e-6 + B / 6.5e12);
+        const double est_gemm = 270e-6 + (double)((nq + 127) / 128) * B / pass_rate;
+        if (est_scan < est_gemm) gemm = false;
+    }
     if (gemm) G.batched_queries += nq;
     if (gemm) return search_gemm_path(tv, g, t.dpad, nq, q_dev, k, out_ids, out_scores, out_counts, st, ws);
     return search_scan_path(tv, g, t.dpad, nq, q_dev, k, out_ids, out_scores, out_counts, st, ws);
