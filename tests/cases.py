@@ -66,3 +66,21 @@ def run_oracle(case):
     stored = O.prepare_store(rows, METRICS[metric], DTYPES[dtype])
     res = O.search(stored, ids, queries, k, METRICS[metric])
     return rows, ids, queries, res
+
+
+def oracle_search(stored, ids, queries, k, metric):
+    """Oracle answer per query.  Small cases use the numpy oracle directly; large ones score with the
+    C restatement (OpenMP), which tests/test_oracle.py pins bit for bit to the numpy oracle, and rank
+    with the numpy oracle's (score, id) order."""
+    from oracle import oracle as O
+    queries = np.ascontiguousarray(queries, dtype=np.float32)
+    if queries.ndim == 1:
+        queries = queries[None, :]
+    if stored.shape[0] * stored.shape[1] * queries.shape[0] < 2e8:
+        return O.search(stored, ids, queries, k, metric)
+    from oracle import oracle_c as OC
+    out = []
+    for q in queries:
+        qp = O.prepare_query(q, metric)
+        out.append(O.topk(OC.scores(stored, qp, metric), ids, k, metric))
+    return out

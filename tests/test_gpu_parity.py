@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 def _check(engine, name, stored, ids, queries, k, metric):
     got_ids, got_sc, got_cnt = engine.search(name, queries, k)
-    want = O.search(stored, ids, queries, k, metric)
+    want = cases.oracle_search(stored, ids, queries, k, metric)
     for qi, (wi, ws) in enumerate(want):
         c = int(got_cnt[qi])
         assert c == len(wi), "query %d: count %d != %d" % (qi, c, len(wi))
