@@ -64,7 +64,7 @@ extern "C" {
 int vdb_init(int device);
 int vdb_shutdown(void);
 /* Knobs of /root/reference/server_config.yaml, forwarded by the host shim after it has read
- * that file: "use_blas_threshold" (:36, batch size from which the MFMA GEMM path is used; default 3),
+ * that file: "use_blas_threshold" (:36, batch size from which the MFMA GEMM path is considered; default 2),
  * "cache_capacity_gb" (:42, HBM budget for all tables, 0 = unlimited),
  * "insert_buffer_size_gb" (:19, pinned host staging for host inserts).
  * Launch tunables of the scan kernel (defaults are the measured best): "scan_nt",

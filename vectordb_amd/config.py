@@ -7,8 +7,8 @@ in `raw` so that an existing file loads unchanged.
 
   engine_config.use_blas_threshold (server_config.yaml:36)  batch size from which batched
       queries use the MFMA GEMM path instead of the per-query scan.  The reference's file says 20
-      (the external engine's CPU BLAS crossover); here one GEMM pass costs about two scans, so
-      the built-in default is 3 and a deployment that keeps the reference's file should lower it
+      (the external engine's CPU BLAS crossover); here one batched pass costs 1.4 to 3 scans and the
+      library compares both estimates per call, so the built-in default is 2 and a deployment that keeps the reference's file should lower it
   gpu_resource_config.enable (:41)           must be true: there is no CPU engine
   gpu_resource_config.cache_capacity (:42)   GB of HBM the tables may occupy (0 = no cap)
   gpu_resource_config.search_resources (:43-44)  `gpuN` entries: the shard set; a process binds
@@ -31,7 +31,7 @@ _GPU_RE = re.compile(r"^gpu(\d+)$")
 
 @dataclass
 class EngineConfig:
-    use_blas_threshold: int = 3          # this engine's measured crossover; the file's value wins when present
+    use_blas_threshold: int = 2          # this engine's measured crossover; the file's value wins when present
     gpu_search_threshold: int = 1000
     gpu_enable: bool = True
     cache_capacity_gb: float = 0.0

@@ -818,7 +818,7 @@ static hipError_t launch_wide(const Gemm16Params& p, int nq, int n_cu, hipStream
 // xh*qh + xh*ql + xl*qh, leaving a relative error of 3 * 2^-16 per term against 16 x the fp32 MFMA
 // rate / 3.  A workgroup of 8 waves owns 256 rows x 128 queries (64 x 64 per wave), LDS tiles are
 // double-buffered, two k-steps of operands ride in registers across tile boundaries.
-constexpr int SB_M = 256, SB_N = 128, SB_K = 32, SB_LD = SB_K + 8;     // LDS row = 40 halfs = 80 bytes
+constexpr int SB_M = 256, SB_K = 32, SB_LD = SB_K + 8;     // LDS row = 40 halfs = 80 bytes
 typedef __bf16 bf16x2g __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2g __attribute__((ext_vector_type(2)));
 
@@ -857,15 +857,23 @@ __device__ __forceinline__ void split4_bf16(const f32x4& x, u32x2g& hi, u32x2g& 
     lo[0] = (unsigned int)l[0] | ((unsigned int)l[1] << 16); lo[1] = (unsigned int)l[2] | ((unsigned int)l[3] << 16);
 }
 
+// NB = 32-query blocks per workgroup tile: 4 (128 queries, 64 x 64 per wave), 2 (64 queries, 64 x 32
+// per wave) or 1 (32 queries, 32 x 32 per wave; small batches then cost little more than reading
+// the rows once).  The tile is 256 rows in every case.
+template <int NB>
 __global__ void __launch_bounds__(512, 1)
 gemm32s_kernel(Gemm32sParams p) {
+    constexpr int TN = 32 * NB;                    // queries per tile
+    constexpr int NI = NB == 4 ? 2 : 1;            // 32-query blocks per wave
+    constexpr int MI = NB == 1 ? 1 : 2;            // 32-row blocks per wave
+    constexpr int WN = NB / NI;                    // waves across the queries
     extern __shared__ __attribute__((aligned(16))) unsigned short ssm[];
     unsigned short* Ah = ssm;                                  // [2][SB_M * SB_LD]
     unsigned short* Al = Ah + 2 * SB_M * SB_LD;
-    unsigned short* Bh = Al + 2 * SB_M * SB_LD;                // [2][SB_N * SB_LD]
-    unsigned short* Bl = Bh + 2 * SB_N * SB_LD;
+    unsigned short* Bh = Al + 2 * SB_M * SB_LD;                // [2][TN * SB_LD]
+    unsigned short* Bl = Bh + 2 * TN * SB_LD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
     const int qt = blockIdx.y;
     const int nks = (p.dpad + SB_K - 1) / SB_K;
@@ -878,14 +886,15 @@ gemm32s_kernel(Gemm32sParams p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) { const int f = tid + 512 * i; arow[i] = f >> 3; ac[i] = f & 7; }
     const int brow = tid >> 2, bc = tid & 3;
-    int qb = qt * SB_N + brow;
+    const bool bstage = tid < TN * 4;              // threads that stage a query chunk
+    int qb = qt * TN + (bstage ? brow : 0);
     if (qb > p.nq - 1) qb = p.nq - 1;
     const unsigned short* qh = p.Qhi + (size_t)qb * p.qstride;
     const unsigned short* ql = p.Qlo + (size_t)qb * p.qstride;
-    float thr[2];
+    float thr[NI];
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int q = qt * SB_N + wn * 64 + ni * 32 + li;
+    for (int ni = 0; ni < NI; ++ni) {
+        const int q = qt * TN + (wn * NI + ni) * 32 + li;
         thr[ni] = (q < p.nq) ? p.thr[q] : __builtin_huge_valf();
     }
 
@@ -912,15 +921,17 @@ gemm32s_kernel(Gemm32sParams p) {
         }
         const int c8 = f_ks * (SB_K / 8) + bc;
         const bool okq = live && c8 < q8;
-        rh[u] = *(const u32x4g*)(okq ? qh + c8 * 8 : (const unsigned short*)g_zero16);
-        rl[u] = *(const u32x4g*)(okq ? ql + c8 * 8 : (const unsigned short*)g_zero16);
+        if (NB == 4 || bstage) {
+            rh[u] = *(const u32x4g*)(okq ? qh + c8 * 8 : (const unsigned short*)g_zero16);
+            rl[u] = *(const u32x4g*)(okq ? ql + c8 * 8 : (const unsigned short*)g_zero16);
+        }
         --f_left;
         if (++f_ks == nks) { f_ks = 0; f_tile += gridDim.x; }
     };
     fetch(0);
     fetch(1);
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][NI];
     long long c_tile = blockIdx.x;
     int c_ks = 0;
     for (long long s0 = 0; s0 < padded; s0 += 2) {
@@ -929,8 +940,8 @@ gemm32s_kernel(Gemm32sParams p) {
             // every wave finished reading buffer u (two k-steps ago) before it passed the last barrier
             unsigned short* Ahu = Ah + u * (SB_M * SB_LD);
             unsigned short* Alu = Al + u * (SB_M * SB_LD);
-            unsigned short* Bhu = Bh + u * (SB_N * SB_LD);
-            unsigned short* Blu = Bl + u * (SB_N * SB_LD);
+            unsigned short* Bhu = Bh + u * (TN * SB_LD);
+            unsigned short* Blu = Bl + u * (TN * SB_LD);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 u32x2g h2, l2;
@@ -938,35 +949,37 @@ gemm32s_kernel(Gemm32sParams p) {
                 *(u32x2g*)&Ahu[arow[i] * SB_LD + ac[i] * 4] = h2;
                 *(u32x2g*)&Alu[arow[i] * SB_LD + ac[i] * 4] = l2;
             }
-            *(u32x4g*)&Bhu[brow * SB_LD + bc * 8] = rh[u];
-            *(u32x4g*)&Blu[brow * SB_LD + bc * 8] = rl[u];
+            if (NB == 4 || bstage) {
+                *(u32x4g*)&Bhu[brow * SB_LD + bc * 8] = rh[u];
+                *(u32x4g*)&Blu[brow * SB_LD + bc * 8] = rl[u];
+            }
             fetch(u);
             __syncthreads();
             if (c_ks == 0) {
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
+                for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < 2; ++ni)
+                    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
             }
 #pragma unroll
             for (int kk = 0; kk < SB_K / 16; ++kk) {
-                u32x4g ah[2], al[2], bh[2], bl[2];
+                u32x4g ah[MI], al[MI], bh[NI], bl[NI];
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi) {
-                    ah[mi] = *(const u32x4g*)&Ahu[(wm * 64 + mi * 32 + li) * SB_LD + kk * 16 + lh * 8];
-                    al[mi] = *(const u32x4g*)&Alu[(wm * 64 + mi * 32 + li) * SB_LD + kk * 16 + lh * 8];
+                for (int mi = 0; mi < MI; ++mi) {
+                    ah[mi] = *(const u32x4g*)&Ahu[((wm * MI + mi) * 32 + li) * SB_LD + kk * 16 + lh * 8];
+                    al[mi] = *(const u32x4g*)&Alu[((wm * MI + mi) * 32 + li) * SB_LD + kk * 16 + lh * 8];
                 }
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    bh[ni] = *(const u32x4g*)&Bhu[(wn * 64 + ni * 32 + li) * SB_LD + kk * 16 + lh * 8];
-                    bl[ni] = *(const u32x4g*)&Blu[(wn * 64 + ni * 32 + li) * SB_LD + kk * 16 + lh * 8];
+                for (int ni = 0; ni < NI; ++ni) {
+                    bh[ni] = *(const u32x4g*)&Bhu[((wn * NI + ni) * 32 + li) * SB_LD + kk * 16 + lh * 8];
+                    bl[ni] = *(const u32x4g*)&Blu[((wn * NI + ni) * 32 + li) * SB_LD + kk * 16 + lh * 8];
                 }
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
+                for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < 2; ++ni) {
+                    for (int ni = 0; ni < NI; ++ni) {
                         acc[mi][ni] = mfma16<VDB_BF16>(al[mi], bh[ni], acc[mi][ni]);
                         acc[mi][ni] = mfma16<VDB_BF16>(ah[mi], bl[ni], acc[mi][ni]);
                         acc[mi][ni] = mfma16<VDB_BF16>(ah[mi], bh[ni], acc[mi][ni]);
@@ -979,10 +992,10 @@ gemm32s_kernel(Gemm32sParams p) {
                 c_tile += gridDim.x;
                 const long long left = p.n - row0;
                 const int nloc = left < SB_M ? (int)left : SB_M;
-                const int q0 = qt * SB_N + wn * 64 + li;
+                const int q0 = qt * TN + wn * NI * 32 + li;
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi) {
-                    const int lr0 = wm * 64 + mi * 32 + 4 * lh;       // this lane's rows: lr0 + (r&3) + 8*(r>>2)
+                for (int mi = 0; mi < MI; ++mi) {
+                    const int lr0 = (wm * MI + mi) * 32 + 4 * lh;     // this lane's rows: lr0 + (r&3) + 8*(r>>2)
                     float rn2[16];
                     if (p.l2) {
                         const float* n2p = p.n2 + row0 + lr0;
@@ -993,7 +1006,7 @@ gemm32s_kernel(Gemm32sParams p) {
                         }
                     }
 #pragma unroll
-                    for (int ni = 0; ni < 2; ++ni) {
+                    for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             float key = acc[mi][ni][r];
@@ -1014,6 +1027,24 @@ gemm32s_kernel(Gemm32sParams p) {
     }
 }
 
+template <int NB>
+static hipError_t launch_gemm32s_nb(const Gemm32sParams& p, int nq, int n_cu, hipStream_t st) {
+    const size_t lds = (size_t)2 * (2 * SB_M + 2 * 32 * NB) * SB_LD * sizeof(unsigned short);
+    static bool allowed = false;
+    if (!allowed) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm32s_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        allowed = true;
+    }
+    const int qtiles = (nq + 32 * NB - 1) / (32 * NB);
+    long long gx = (long long)n_cu / qtiles;                  // one workgroup per CU
+    gx = gx / 8 * 8;                                          // query tiles of one row range share an XCD
+    if (gx < 8) gx = 8;
+    if (gx > p.ntiles) gx = p.ntiles;
+    hipLaunchKernelGGL((gemm32s_kernel<NB>), dim3((unsigned)gx, (unsigned)qtiles), dim3(512), lds, st, p);
+    return hipGetLastError();
+}
+
 // Full pass over an fp32 table with the kernel above; qhi/qlo from launch_split_query16 (bf16,
 // stride qstride).
 hipError_t launch_gemm32s(const TableView& t, const unsigned short* qhi, const unsigned short* qlo, int qstride,
@@ -1024,20 +1055,9 @@ hipError_t launch_gemm32s(const TableView& t, const unsigned short* qhi, const u
     p.dpad = dpad; p.qstride = qstride; p.ldx = t.m * 4; p.l2 = t.metric == VDB_METRIC_L2 ? 1 : 0;
     p.ntiles = (t.n + SB_M - 1) / SB_M;
     p.cand_s = cand_s; p.cand_t = cand_t; p.cnt = cnt; p.lost = lost; p.cap = cap;
-    const size_t lds = (size_t)2 * (2 * SB_M + 2 * SB_N) * SB_LD * sizeof(unsigned short);
-    static bool allowed = false;
-    if (!allowed) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm32s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        allowed = true;
-    }
-    const int qtiles = (nq + SB_N - 1) / SB_N;
-    long long gx = (long long)n_cu / qtiles;                  // one workgroup per CU
-    gx = gx / 8 * 8;                                          // query tiles of one row range share an XCD
-    if (gx < 8) gx = 8;
-    if (gx > p.ntiles) gx = p.ntiles;
-    hipLaunchKernelGGL(gemm32s_kernel, dim3((unsigned)gx, (unsigned)qtiles), dim3(512), lds, st, p);
-    return hipGetLastError();
+    if (nq <= 32) return launch_gemm32s_nb<1>(p, nq, n_cu, st);
+    if (nq <= 64) return launch_gemm32s_nb<2>(p, nq, n_cu, st);
+    return launch_gemm32s_nb<4>(p, nq, n_cu, st);
 }
 
 // 0 = choose by shape, 1 = streaming kernel, 11 = LDS-staged tile kernel, 12 = wide-tile kernel

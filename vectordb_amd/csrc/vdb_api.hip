@@ -76,7 +76,7 @@ struct Global {
     std::vector<std::unique_ptr<Workspace>> free_ws;
     long long* d_counters = nullptr;
     // options
-    int use_blas_threshold = 3;          // measured crossover: one GEMM pass costs about two scans
+    int use_blas_threshold = 2;          // a batched pass costs 1.4 (fp32) to 3 (bf16) scans: see search_core
     double cache_capacity_gb = 0.0;
     double insert_buffer_gb = 1.0;
     size_t table_bytes = 0;
@@ -424,7 +424,8 @@ static int search_core(Table& t, int64_t nq, const float* q_dev, int k, long lon
         // Small tables: a batched pass has a fixed cost (threshold passes, flat finalize) that a
         // few scans undercut.  Both estimates are fits of measured times (seconds; row bytes B).
         const double B = (double)tv.n * tv.m * 16.0;
-        const double pass_rate = tv.dt == VDB_F32 ? 3.8e12 : (tv.dt == VDB_BF16 || G.tune_split_f16 ? 2.3e12 : 4.0e12);
+        const double pass_rate = tv.dt == VDB_F32 ? (nq <= 32 ? 5.0e12 : nq <= 64 ? 4.2e12 : 3.8e12)
+                                                  : (tv.dt == VDB_BF16 || G.tune_split_f16 ? 2.3e12 : 4.0e12);
         const double est_scan = 60e-6 + (double)nq * (20e-6 + B / 6.5e12);
         const double est_gemm = 270e-6 + (double)((nq + 127) / 128) * B / pass_rate;
         if (est_scan < est_gemm) gemm = false;
