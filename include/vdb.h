@@ -77,7 +77,8 @@ int vdb_shutdown(void);
  * "gemm32_split" (1 = fp32 tables, 64 queries or more: full pass on the 16-bit MFMA with bf16 hi + lo
  * operands, three products per term; 0 = fp32 MFMA),
  * "gemm16_variant" (0 = chosen by shape, 1 = register-streaming kernel, 11 = 128x128 LDS-tiled
- * kernel, 12 = 256x256 wide-tile kernel for full passes over more than 128 queries). */
+ * kernel, 12 = 256x256 wide-tile kernel for full passes over more than 128 queries, 13 = the 256-row
+ * kernel of the fp32 tables). */
 int vdb_set_option(const char* key, double value);
 const char* vdb_last_error(void);
 

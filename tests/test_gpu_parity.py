@@ -418,10 +418,11 @@ def test_batched_gemm_path_16bit_parity(engine, table_name, metric, dtype, d, nq
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
-@pytest.mark.parametrize("variant", [1, 11, 12])
+@pytest.mark.parametrize("variant", [1, 11, 12, 13])
 def test_each_16bit_gemm_kernel_parity(engine, table_name, variant, dtype):
-    """The library picks one of three 16-bit batched kernels by shape (128 x 128 LDS-staged tile
-    kernel, row fragments streamed straight to registers, 256 x 256 wide-tile kernel); forced
+    """The library picks one of four 16-bit batched kernels by shape (128 x 128 LDS-staged tile
+    kernel, row fragments streamed straight to registers, 256 x 256 wide-tile kernel, the 256-row
+    kernel shared with the fp32 tables); forced
     through the `gemm16_variant` option each must give the same exact results for split (bf16)
     and unsplit (fp16) queries.  150 queries: more than one 128-query tile, a ragged last tile."""
     n, d, nq = 70_000, 200, 150

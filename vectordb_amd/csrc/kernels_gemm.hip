@@ -823,14 +823,14 @@ typedef __bf16 bf16x2g __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2g __attribute__((ext_vector_type(2)));
 
 struct Gemm32sParams {
-    const float* X;              // [n][ldx] fp32 rows
+    const void*  X;              // [n][ldx] rows: fp32 (MODE 0) or 16-bit (MODE 1, 2)
     const float* n2;
     const unsigned short* Qhi;   // [nq][qstride] bf16, zero padded to a multiple of 8
     const unsigned short* Qlo;
     const float* thr;
     long long    n;
     int          nq;
-    int          dpad;           // floats per row (multiple of 4)
+    int          dpad;           // elements per row (multiple of 4 for fp32 rows, of 8 for 16-bit rows)
     int          qstride;        // halfs per query row (multiple of 8)
     int          ldx;
     int          l2;
@@ -860,31 +860,37 @@ __device__ __forceinline__ void split4_bf16(const f32x4& x, u32x2g& hi, u32x2g& 
 // NB = 32-query blocks per workgroup tile: 4 (128 queries, 64 x 64 per wave), 2 (64 queries, 64 x 32
 // per wave) or 1 (32 queries, 32 x 32 per wave; small batches then cost little more than reading
 // the rows once).  The tile is 256 rows in every case.
-template <int NB>
+// MODE 0: fp32 rows split into bf16 hi + lo, split query, three products per term;
+// MODE 1: 16-bit rows as stored, split query, two products; MODE 2: 16-bit rows, query hi only.
+// DT is the 16-bit type the MFMA multiplies in (bf16 for MODE 0, the table's type otherwise).
+template <int NB, int DT, int MODE>
 __global__ void __launch_bounds__(512, 1)
 gemm32s_kernel(Gemm32sParams p) {
+    constexpr int NA = MODE == 0 ? 4 : 2;          // 16-byte row chunks staged per thread and k-step
+    constexpr int CPR = MODE == 0 ? 8 : 4;         // 16-byte chunks per tile row and k-step
+    constexpr int EPC = MODE == 0 ? 4 : 8;         // elements per chunk
     constexpr int TN = 32 * NB;                    // queries per tile
     constexpr int NI = NB == 4 ? 2 : 1;            // 32-query blocks per wave
     constexpr int MI = NB == 1 ? 1 : 2;            // 32-row blocks per wave
     constexpr int WN = NB / NI;                    // waves across the queries
     extern __shared__ __attribute__((aligned(16))) unsigned short ssm[];
     unsigned short* Ah = ssm;                                  // [2][SB_M * SB_LD]
-    unsigned short* Al = Ah + 2 * SB_M * SB_LD;
-    unsigned short* Bh = Al + 2 * SB_M * SB_LD;                // [2][TN * SB_LD]
-    unsigned short* Bl = Bh + 2 * TN * SB_LD;
+    unsigned short* Al = Ah + 2 * SB_M * SB_LD;                // MODE 0 only
+    unsigned short* Bh = Al + (MODE == 0 ? 2 * SB_M * SB_LD : 0);   // [2][TN * SB_LD]
+    unsigned short* Bl = Bh + 2 * TN * SB_LD;                  // MODE 0, 1
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
     const int qt = blockIdx.y;
     const int nks = (p.dpad + SB_K - 1) / SB_K;
-    const int d4 = p.dpad >> 2;                    // 4-float chunks per row
+    const int dch = p.dpad / EPC;                  // 16-byte chunks per row
     const int q8 = p.qstride >> 3;                 // 8-half chunks per query row
 
-    // staging: row chunks f = tid + 512 * i (i < 4): tile row f / 8, 4-float chunk f % 8;
+    // staging: row chunks f = tid + 512 * i (i < NA): tile row f / CPR, chunk f % CPR;
     //          query chunk tid: tile query tid / 4, 8-half chunk tid % 4
-    int arow[4], ac[4];
+    int arow[NA], ac[NA];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { const int f = tid + 512 * i; arow[i] = f >> 3; ac[i] = f & 7; }
+    for (int i = 0; i < NA; ++i) { const int f = tid + 512 * i; arow[i] = f / CPR; ac[i] = f % CPR; }
     const int brow = tid >> 2, bc = tid & 3;
     const bool bstage = tid < TN * 4;              // threads that stage a query chunk
     int qb = qt * TN + (bstage ? brow : 0);
@@ -902,7 +908,7 @@ gemm32s_kernel(Gemm32sParams p) {
     const long long total = my_tiles * nks;
     const long long padded = (total + 1) / 2 * 2;
 
-    f32x4 ra[2][4];
+    u32x4g ra[2][NA];                              // raw 16 bytes: 4 fp32 or 8 16-bit values
     u32x4g rh[2], rl[2];
     long long f_tile = blockIdx.x;
     int f_ks = 0;
@@ -911,19 +917,20 @@ gemm32s_kernel(Gemm32sParams p) {
         const bool live = f_left > 0;
         const long long row0 = f_tile * SB_M;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NA; ++i) {
             long long r = row0 + arow[i];
             if (r > p.n - 1) r = p.n - 1;
-            const int c4 = f_ks * (SB_K / 4) + ac[i];
+            const int ch = f_ks * CPR + ac[i];
             // past the row's end the row operand re-reads the row's first bytes: the query operand is zero there
-            const float* xa = live ? p.X + (size_t)r * p.ldx + (c4 < d4 ? c4 * 4 : 0) : (const float*)g_zero16;
-            ra[u][i] = __builtin_nontemporal_load((const f32x4*)xa);
+            const char* xa = live ? (const char*)p.X + ((size_t)r * p.ldx + (ch < dch ? ch * EPC : 0)) * (MODE == 0 ? 4 : 2)
+                                  : (const char*)g_zero16;
+            ra[u][i] = __builtin_nontemporal_load((const u32x4g*)xa);
         }
         const int c8 = f_ks * (SB_K / 8) + bc;
         const bool okq = live && c8 < q8;
         if (NB == 4 || bstage) {
             rh[u] = *(const u32x4g*)(okq ? qh + c8 * 8 : (const unsigned short*)g_zero16);
-            rl[u] = *(const u32x4g*)(okq ? ql + c8 * 8 : (const unsigned short*)g_zero16);
+            if (MODE != 2) rl[u] = *(const u32x4g*)(okq ? ql + c8 * 8 : (const unsigned short*)g_zero16);
         }
         --f_left;
         if (++f_ks == nks) { f_ks = 0; f_tile += gridDim.x; }
@@ -943,15 +950,19 @@ gemm32s_kernel(Gemm32sParams p) {
             unsigned short* Bhu = Bh + u * (TN * SB_LD);
             unsigned short* Blu = Bl + u * (TN * SB_LD);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                u32x2g h2, l2;
-                split4_bf16(ra[u][i], h2, l2);
-                *(u32x2g*)&Ahu[arow[i] * SB_LD + ac[i] * 4] = h2;
-                *(u32x2g*)&Alu[arow[i] * SB_LD + ac[i] * 4] = l2;
+            for (int i = 0; i < NA; ++i) {
+                if constexpr (MODE == 0) {
+                    u32x2g h2, l2;
+                    split4_bf16(__builtin_bit_cast(f32x4, ra[u][i]), h2, l2);
+                    *(u32x2g*)&Ahu[arow[i] * SB_LD + ac[i] * 4] = h2;
+                    *(u32x2g*)&Alu[arow[i] * SB_LD + ac[i] * 4] = l2;
+                } else {
+                    *(u32x4g*)&Ahu[arow[i] * SB_LD + ac[i] * 8] = ra[u][i];
+                }
             }
             if (NB == 4 || bstage) {
                 *(u32x4g*)&Bhu[brow * SB_LD + bc * 8] = rh[u];
-                *(u32x4g*)&Blu[brow * SB_LD + bc * 8] = rl[u];
+                if (MODE != 2) *(u32x4g*)&Blu[brow * SB_LD + bc * 8] = rl[u];
             }
             fetch(u);
             __syncthreads();
@@ -969,20 +980,20 @@ gemm32s_kernel(Gemm32sParams p) {
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
                     ah[mi] = *(const u32x4g*)&Ahu[((wm * MI + mi) * 32 + li) * SB_LD + kk * 16 + lh * 8];
-                    al[mi] = *(const u32x4g*)&Alu[((wm * MI + mi) * 32 + li) * SB_LD + kk * 16 + lh * 8];
+                    if (MODE == 0) al[mi] = *(const u32x4g*)&Alu[((wm * MI + mi) * 32 + li) * SB_LD + kk * 16 + lh * 8];
                 }
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
                     bh[ni] = *(const u32x4g*)&Bhu[((wn * NI + ni) * 32 + li) * SB_LD + kk * 16 + lh * 8];
-                    bl[ni] = *(const u32x4g*)&Blu[((wn * NI + ni) * 32 + li) * SB_LD + kk * 16 + lh * 8];
+                    if (MODE != 2) bl[ni] = *(const u32x4g*)&Blu[((wn * NI + ni) * 32 + li) * SB_LD + kk * 16 + lh * 8];
                 }
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni) {
-                        acc[mi][ni] = mfma16<VDB_BF16>(al[mi], bh[ni], acc[mi][ni]);
-                        acc[mi][ni] = mfma16<VDB_BF16>(ah[mi], bl[ni], acc[mi][ni]);
-                        acc[mi][ni] = mfma16<VDB_BF16>(ah[mi], bh[ni], acc[mi][ni]);
+                        if (MODE == 0) acc[mi][ni] = mfma16<DT>(al[mi], bh[ni], acc[mi][ni]);
+                        if (MODE != 2) acc[mi][ni] = mfma16<DT>(ah[mi], bl[ni], acc[mi][ni]);
+                        acc[mi][ni] = mfma16<DT>(ah[mi], bh[ni], acc[mi][ni]);
                     }
             }
             if (++c_ks == nks) {
@@ -1027,12 +1038,12 @@ gemm32s_kernel(Gemm32sParams p) {
     }
 }
 
-template <int NB>
+template <int NB, int DT, int MODE>
 static hipError_t launch_gemm32s_nb(const Gemm32sParams& p, int nq, int n_cu, hipStream_t st) {
-    const size_t lds = (size_t)2 * (2 * SB_M + 2 * 32 * NB) * SB_LD * sizeof(unsigned short);
+    const size_t lds = (size_t)2 * ((MODE == 0 ? 2 : 1) * SB_M + (MODE == 2 ? 1 : 2) * 32 * NB) * SB_LD * sizeof(unsigned short);
     static bool allowed = false;
     if (!allowed) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm32s_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm32s_kernel<NB, DT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         allowed = true;
     }
@@ -1041,26 +1052,34 @@ static hipError_t launch_gemm32s_nb(const Gemm32sParams& p, int nq, int n_cu, hi
     gx = gx / 8 * 8;                                          // query tiles of one row range share an XCD
     if (gx < 8) gx = 8;
     if (gx > p.ntiles) gx = p.ntiles;
-    hipLaunchKernelGGL((gemm32s_kernel<NB>), dim3((unsigned)gx, (unsigned)qtiles), dim3(512), lds, st, p);
+    hipLaunchKernelGGL((gemm32s_kernel<NB, DT, MODE>), dim3((unsigned)gx, (unsigned)qtiles), dim3(512), lds, st, p);
     return hipGetLastError();
 }
 
-// Full pass over an fp32 table with the kernel above; qhi/qlo from launch_split_query16 (bf16,
-// stride qstride).
-hipError_t launch_gemm32s(const TableView& t, const unsigned short* qhi, const unsigned short* qlo, int qstride,
-                          int nq, int dpad, const float* thr, float* cand_s, long long* cand_t,
-                          int* cnt, int* lost, int cap, int n_cu, hipStream_t st) {
-    Gemm32sParams p;
-    p.X = (const float*)t.rows; p.n2 = t.n2; p.Qhi = qhi; p.Qlo = qlo; p.thr = thr; p.n = t.n; p.nq = nq;
-    p.dpad = dpad; p.qstride = qstride; p.ldx = t.m * 4; p.l2 = t.metric == VDB_METRIC_L2 ? 1 : 0;
-    p.ntiles = (t.n + SB_M - 1) / SB_M;
-    p.cand_s = cand_s; p.cand_t = cand_t; p.cnt = cnt; p.lost = lost; p.cap = cap;
-    if (nq <= 32) return launch_gemm32s_nb<1>(p, nq, n_cu, st);
-    if (nq <= 64) return launch_gemm32s_nb<2>(p, nq, n_cu, st);
-    return launch_gemm32s_nb<4>(p, nq, n_cu, st);
+template <int DT, int MODE>
+static hipError_t launch_gemm32s_mode(const Gemm32sParams& p, int nq, int n_cu, hipStream_t st) {
+    if (nq <= 32) return launch_gemm32s_nb<1, DT, MODE>(p, nq, n_cu, st);
+    if (nq <= 64) return launch_gemm32s_nb<2, DT, MODE>(p, nq, n_cu, st);
+    return launch_gemm32s_nb<4, DT, MODE>(p, nq, n_cu, st);
 }
 
-// 0 = choose by shape, 1 = streaming kernel, 11 = LDS-staged tile kernel, 12 = wide-tile kernel
+// Full pass over a table with the kernel above.  fp32 tables: qhi/qlo are bf16 (launch_split_query16,
+// stride qstride).  16-bit tables: qhi/qlo in the table's type, `split` says whether qlo is used.
+hipError_t launch_gemm32s(const TableView& t, const unsigned short* qhi, const unsigned short* qlo, int qstride,
+                          int split, int nq, int dpad, const float* thr, float* cand_s, long long* cand_t,
+                          int* cnt, int* lost, int cap, int n_cu, hipStream_t st) {
+    Gemm32sParams p;
+    p.X = t.rows; p.n2 = t.n2; p.Qhi = qhi; p.Qlo = qlo; p.thr = thr; p.n = t.n; p.nq = nq;
+    p.dpad = dpad; p.qstride = qstride; p.ldx = t.dt == VDB_F32 ? t.m * 4 : t.m * 8; p.l2 = t.metric == VDB_METRIC_L2 ? 1 : 0;
+    p.ntiles = (t.n + SB_M - 1) / SB_M;
+    p.cand_s = cand_s; p.cand_t = cand_t; p.cnt = cnt; p.lost = lost; p.cap = cap;
+    if (t.dt == VDB_F32) return launch_gemm32s_mode<VDB_BF16, 0>(p, nq, n_cu, st);
+    if (t.dt == VDB_BF16) return split ? launch_gemm32s_mode<VDB_BF16, 1>(p, nq, n_cu, st) : launch_gemm32s_mode<VDB_BF16, 2>(p, nq, n_cu, st);
+    return split ? launch_gemm32s_mode<VDB_F16, 1>(p, nq, n_cu, st) : launch_gemm32s_mode<VDB_F16, 2>(p, nq, n_cu, st);
+}
+
+// 0 = choose by shape, 1 = streaming kernel, 11 = LDS-staged tile kernel, 12 = wide-tile kernel,
+// 13 = 256-row kernel shared with the fp32 tables
 static int g_gemm16_variant = 0;
 void set_gemm16_variant(int v) { g_gemm16_variant = v; }
 
@@ -1083,15 +1102,20 @@ hipError_t launch_gemm16_thresh(const TableView& t, const unsigned short* qhi, c
     const dim3 grid((unsigned)gx, (unsigned)qtiles), block(256);
     // measured on 20M x 768: the tile kernel wins with an unsplit query up to two query tiles, the
     // streaming kernel with more query tiles or a split query (twice the MFMA work per row byte)
-    // the wide-tile kernel covers full passes (every row tile) over more than one query tile
+    // Full passes (every row tile), measured on 20M x 768 (these kernels run at the speed of their LDS
+    // fragment reads): a split query up to 64 queries takes the 256-row kernel shared with the fp32
+    // tables (32- and 64-query tiles: 9.8 ms against 13.3 ms at 8 queries); more than 128 queries the
+    // wide-tile kernel; otherwise the 128 x 128 tile kernel (unsplit) or the streaming kernel (split).
     const bool full = tile0 == 0 && tile_stride == 1 && ntiles == (t.n + HB_M - 1) / HB_M;
+    if (!dense && full && ((g_gemm16_variant == 0 && split && nq <= 64) || g_gemm16_variant == 13))
+        return launch_gemm32s(t, qhi, qlo, dpad, split, nq, dpad, thr, cand_s, cand_t, cnt, lost, cap, n_cu, st);
     if (!dense && full && nq > HB_N && (g_gemm16_variant == 0 || g_gemm16_variant == 12)) {
         Gemm16Params w = p;
         w.ntiles = (t.n + WB_M - 1) / WB_M;
         if (t.dt == VDB_BF16) return split ? launch_wide<VDB_BF16, true>(w, nq, n_cu, st) : launch_wide<VDB_BF16, false>(w, nq, n_cu, st);
         return split ? launch_wide<VDB_F16, true>(w, nq, n_cu, st) : launch_wide<VDB_F16, false>(w, nq, n_cu, st);
     }
-    const bool stream = g_gemm16_variant == 1 || (g_gemm16_variant == 0 && (split || nq > 2 * HB_N));
+    const bool stream = g_gemm16_variant == 1 || (g_gemm16_variant == 0 && split);
     if (stream && !dense) {
         if (t.dt == VDB_BF16) {
             if (split) hipLaunchKernelGGL((gemm16_stream_kernel<VDB_BF16, true>), grid, block, 0, st, p);

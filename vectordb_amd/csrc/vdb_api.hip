@@ -390,7 +390,7 @@ static int search_gemm_path(const TableView& tv, const SelGeom& g, int dpad, int
         VDB_HIP(hipMemsetAsync(cnt, 0, (size_t)nqc * 8, st));
         ProfScope prof;
         if ((rc = prof.begin(st))) return rc;
-        if (s32) VDB_HIP(launch_gemm32s(tv, qhi, qlo, qstride, nqi, dpad, tau, cs, ct, cnt, lost, GEMM_CAP, G.n_cu, st));
+        if (s32) VDB_HIP(launch_gemm32s(tv, qhi, qlo, qstride, 1, nqi, dpad, tau, cs, ct, cnt, lost, GEMM_CAP, G.n_cu, st));
         else VDB_HIP(gemm(tv, tau, 1, ntiles, 0));
         if ((rc = prof.end(st))) return rc;
         VDB_HIP(launch_finalize_flat(tv, qprep, qinfo, nqi, dpad, g, k, cs, ct, cnt, GEMM_CAP, tau, lost, bad, fb,
@@ -425,7 +425,7 @@ static int search_core(Table& t, int64_t nq, const float* q_dev, int k, long lon
         // few scans undercut.  Both estimates are fits of measured times (seconds; row bytes B).
         const double B = (double)tv.n * tv.m * 16.0;
         const double pass_rate = tv.dt == VDB_F32 ? (nq <= 32 ? 5.0e12 : nq <= 64 ? 4.2e12 : 3.8e12)
-                                                  : (tv.dt == VDB_BF16 || G.tune_split_f16 ? 2.3e12 : 4.0e12);
+                                                  : (tv.dt == VDB_BF16 || G.tune_split_f16 ? (nq <= 64 ? 3.2e12 : 2.3e12) : 4.0e12);
         const double est_scan = 60e-6 + (double)nq * (20e-6 + B / 6.5e12);
         const double est_gemm = 270e-6 + (double)((nq + 127) / 128) * B / pass_rate;
         if (est_scan < est_gemm) gemm = false;
