@@ -546,3 +546,48 @@ def test_batched_fp32_split_with_large_magnitudes_and_ties(engine, table_name):
             _check(engine, name, stored, ids, q, 10, metric)
         finally:
             engine.drop_table(name)
+
+
+@pytest.mark.parametrize("metric,dtype,n,d,k,nq", [
+    ("cosine", "f32", 10_000_000, 768, 10, 4),        # headline / BASELINE config 2 shape at 10M
+    ("cosine", "f32", 10_000_000, 768, 10, 1024),     # config 3: batch 1024
+    ("ip", "bf16", 12_500_000, 128, 100, 3),          # config 4: one shard of 100M / 8
+    ("l2", "f16", 20_000_000, 768, 10, 256),          # config 5
+])
+def test_full_size_properties(engine, table_name, metric, dtype, n, d, k, nq):
+    """BASELINE's own sizes, through size-independent properties: scores are the canonical scores of
+    the returned rows (regenerated and quantised on the host), order is (score, id), a planted copy
+    of a stored row comes first, no row of a 100k-row sample beats the k-th hit, and the per-query
+    scan and the batched path agree bit for bit."""
+    from oracle import oracle_c as OC
+    m, dt = cases.METRICS[metric], cases.DTYPES[dtype]
+    engine.create_table(table_name, d, m, dt)
+    engine.reserve(table_name, n)
+    engine.insert_synthetic(table_name, n, seed=0, first_row=0)
+    q = OC.synth_rows(1, 0, nq, d)
+    planted = 7_654_321
+    q[nq - 1] = OC.synth_rows(0, planted, 1, d)[0]
+    ids_b, sc_b, cnt_b = engine.search(table_name, q, k)            # batched path (nq >= 2)
+    assert list(cnt_b) == [k] * nq
+    check = sorted(set([0, 1, nq // 2, nq - 2, nq - 1]) & set(range(nq)))
+    engine.set_option("gemm_path", 0)
+    try:
+        ids, sc, cnt = engine.search(table_name, q[check], k)       # one scan per checked query
+    finally:
+        engine.set_option("gemm_path", 1)
+    assert np.array_equal(ids, ids_b[check]) and np.array_equal(sc.view(np.uint32), sc_b[check].view(np.uint32))
+    if metric != "l2":
+        assert ids_b[nq - 1, 0] == planted
+    else:
+        assert ids_b[nq - 1, 0] == planted and sc_b[nq - 1, 0] <= 1e-2    # fp16 rounding of the stored copy
+    for j, qi in enumerate(check):
+        qp = O.prepare_query(q[qi], m)
+        raw = np.concatenate([OC.synth_rows(0, int(r), 1, d) for r in ids[j]])
+        want = OC.scores(O.prepare_store(raw, m, dt), qp, m)
+        assert np.array_equal(want.view(np.uint32), sc[j].view(np.uint32))
+        key = sc[j] if metric == "l2" else -sc[j]
+        assert np.array_equal(np.lexsort((ids[j], key)), np.arange(k))
+        s0 = 1_000_000 + j * 2_000_000
+        ssc = OC.scores(O.prepare_store(OC.synth_rows(0, s0, 100_000, d), m, dt), qp, m)
+        better = np.nonzero(ssc < sc[j, k - 1] if metric == "l2" else ssc > sc[j, k - 1])[0] + s0
+        assert set(better.tolist()) <= set(ids[j].tolist())
