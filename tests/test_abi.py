@@ -106,3 +106,15 @@ def test_snapshot_file_names_stay_inside_primary_path():
     # not connected: the snapshot calls answer with a status like every other call
     m = M.Milvus()
     assert not m.snapshot("demo").OK() and not m.preload_table("demo").OK()
+
+
+def test_bench_cpu_baseline_leg_runs_on_a_small_sample():
+    """bench.py's cpu_baseline leg (the oracle's BLAS path, the only part of bench.py that may use
+    oracle/) returns the fields the bench line needs."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    out = bench.cpu_baseline(rows_total=20_000, dim=64, k=10, metric_name="cosine", budget_s=0.2)
+    assert out["unit"] == "QPS" and out["kind"] == "port" and out["value"] > 0 and out["cores"] >= 1
+    assert "sample" in out and "20000" in out["sample"]
