@@ -66,7 +66,7 @@ int vdb_shutdown(void);
 /* Knobs of /root/reference/server_config.yaml, forwarded by the host shim after it has read
  * that file: "use_blas_threshold" (:36, batch size from which the MFMA GEMM path is considered; default 2),
  * "cache_capacity_gb" (:42, HBM budget for all tables, 0 = unlimited),
- * "insert_buffer_size_gb" (:19, pinned host staging for host inserts).
+ * "insert_buffer_size_gb" (:19, size of the device staging buffer host inserts are chunked through).
  * Launch tunables of the scan kernel (defaults are the measured best): "scan_nt",
  * "scan_waves", "scan_blocks_per_cu", "scan_contiguous"; "scan_serialize" (1 = scans issued on
  * different streams run one after the other, chained by events, while the short kernels around
