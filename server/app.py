@@ -31,6 +31,8 @@ from flask import Flask, request
 
 from milvus import IndexType, MetricType, Milvus
 from server.metastore import MetaStore, MetaStoreError
+from vectordb_amd.cluster import ClusterMilvus
+from vectordb_amd.config import load_config
 from vectordb_amd.hashing import hash_vector
 
 _HOST = "127.0.0.1"       # kept for the connect() call; the engine runs in this process
@@ -48,7 +50,9 @@ def create_app(client: Milvus = None, store: MetaStore = None) -> Flask:
     def engine() -> Milvus:
         with lock:
             if state["client"] is None:
-                m = Milvus()
+                # several devices in gpu_resource_config.search_resources: one worker process per GPU
+                cfg = load_config()
+                m = ClusterMilvus(cfg) if len(cfg.search_resources) > 1 else Milvus()
                 status = m.connect(host=_HOST, port=_PORT)
                 if not status.OK():
                     print("Server connect fail.", status.message)

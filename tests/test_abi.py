@@ -118,3 +118,14 @@ def test_bench_cpu_baseline_leg_runs_on_a_small_sample():
     out = bench.cpu_baseline(rows_total=20_000, dim=64, k=10, metric_name="cosine", budget_s=0.2)
     assert out["unit"] == "QPS" and out["kind"] == "port" and out["value"] > 0 and out["cores"] >= 1
     assert "sample" in out and "20000" in out["sample"]
+
+
+@pytest.mark.skipif(_gpu(), reason="checks the no-GPU failure path")
+def test_cluster_client_reports_a_missing_gpu_as_a_status():
+    from vectordb_amd.cluster import ClusterMilvus
+    c = ClusterMilvus(EngineConfig(search_resources=[0, 1]))
+    st = c.connect(host="127.0.0.1", port="19530")
+    assert not st.OK() and st.code == _lib.ENOGPU and not c.connected()
+    assert not c.create_table({"table_name": "a", "dimension": 4}).OK()
+    st, res = c.search_vectors(table_name="a", query_records=[[0.0] * 4], top_k=3)
+    assert not st.OK() and res == []

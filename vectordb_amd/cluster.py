@@ -1,0 +1,279 @@
+"""One engine client over several GPUs: the devices of gpu_resource_config.search_resources
+(/root/reference/server_config.yaml:43-44), which the engine the reference configures uses from one
+server process.
+
+Here every GPU gets its own worker process (the library binds a process to one device), each
+holding one row shard of every table behind the ordinary in-process client.  `ClusterMilvus` has
+the surface of that client (the seven calls of /root/reference/app.py plus the additions) and
+
+  * sends table lifecycle calls to every worker,
+  * appends new rows to the least-filled shard (bulk inserts are split evenly),
+  * sends a search to all workers at once and merges the per-shard answers by
+    (score best first, id ascending) -- the order each shard already uses, so the merged top-k
+    equals the answer of one table holding all rows.
+
+The collective-based variant for device-resident callers is vectordb_amd/sharded.py; this one is for
+the HTTP service, whose queries and answers live in host memory anyway.
+"""
+from __future__ import annotations
+
+import dataclasses
+import multiprocessing as mp
+import os
+import threading
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from .config import EngineConfig, load_config
+from .milvus import MetricType, QueryResult, Status
+
+
+def _worker_main(conn, device: int, cfg: EngineConfig) -> None:
+    """Runs in the worker process: one in-process client on one GPU, requests over a pipe."""
+    os.environ["VDB_DEVICE"] = str(device)
+    from .milvus import Milvus                      # imported here: the parent never loads the library
+    client = Milvus(cfg)
+    status = client.connect()
+    conn.send((status.code, status.message))
+    if not status.OK():
+        return
+    while True:
+        try:
+            msg = conn.recv()
+        except EOFError:
+            break
+        if msg is None:
+            break
+        method, args, kwargs = msg
+        try:
+            if method == "search_arrays":
+                # search without building result objects: (code, message, ids, scores, counts)
+                name, q, k = args
+                try:
+                    ids, sc, cnt = client._eng().search(name, q, k)
+                    conn.send((0, "Success", ids, sc, cnt))
+                except Exception as exc:            # reported, never raised across the pipe
+                    st = client._status(exc)
+                    conn.send((st.code, st.message, None, None, None))
+                continue
+            out = getattr(client, method)(*args, **kwargs)
+            if isinstance(out, tuple):
+                conn.send((out[0].code, out[0].message) + tuple(out[1:]))
+            else:
+                conn.send((out.code, out.message))
+        except Exception as exc:
+            conn.send((_lib.EINVAL, "%s: %s" % (type(exc).__name__, exc)))
+
+
+class ClusterMilvus:
+    def __init__(self, config: Optional[EngineConfig] = None, devices: Optional[Sequence[int]] = None):
+        self._config = config or load_config()
+        self._devices = list(devices) if devices is not None else list(self._config.search_resources)
+        self._workers: List[Tuple[Any, Any]] = []            # (process, pipe)
+        self._lock = threading.Lock()                       # one request at a time per pipe set
+        self._metric: Dict[str, int] = {}
+        self._rows: Dict[str, List[int]] = {}                # rows per shard, for least-filled placement
+
+    # -- plumbing ---------------------------------------------------------------------------
+    def _call_all(self, method: str, *args, **kwargs) -> List[tuple]:
+        for _, pipe in self._workers:
+            pipe.send((method, args, kwargs))
+        return [pipe.recv() for _, pipe in self._workers]
+
+    @staticmethod
+    def _first_failure(replies: List[tuple]) -> Status:
+        for r in replies:
+            if r[0] != 0:
+                return Status(r[0], r[1])
+        return Status()
+
+    # -- connection -------------------------------------------------------------------------
+    def connect(self, host: Optional[str] = None, port: Optional[str] = None, uri: Optional[str] = None,
+                timeout: Optional[int] = None) -> Status:
+        with self._lock:
+            if self._workers:
+                return Status()
+            if not self._devices:
+                return Status(_lib.EINVAL, "no devices in gpu_resource_config.search_resources")
+            ctx = mp.get_context("spawn")                    # never fork a process that may hold a GPU context
+            for shard, dev in enumerate(self._devices):
+                parent, child = ctx.Pipe()
+                # every shard keeps its snapshots in a directory of its own under primary_path
+                cfg = dataclasses.replace(self._config, primary_path=os.path.join(self._config.primary_path, "shard%d" % shard))
+                proc = ctx.Process(target=_worker_main, args=(child, dev, cfg), daemon=True)
+                proc.start()
+                child.close()
+                self._workers.append((proc, parent))
+            replies = [pipe.recv() for _, pipe in self._workers]
+            st = self._first_failure(replies)
+            if not st.OK():
+                self._stop()
+            return st
+
+    def connected(self) -> bool:
+        return bool(self._workers)
+
+    def _stop(self) -> None:
+        for proc, pipe in self._workers:
+            try:
+                pipe.send(None)
+            except (OSError, ValueError):
+                pass
+        for proc, pipe in self._workers:
+            proc.join(timeout=10)
+            if proc.is_alive():
+                proc.terminate()
+            pipe.close()
+        self._workers = []
+
+    def disconnect(self) -> Status:
+        with self._lock:
+            self._stop()
+        return Status()
+
+    def server_version(self) -> Tuple[Status, str]:
+        return Status(), "vectordb_amd cluster client (%d GPUs)" % len(self._devices)
+
+    def _need(self) -> Optional[Status]:
+        return None if self._workers else Status(_lib.ESTATE, "not connected")
+
+    # -- table lifecycle ---------------------------------------------------------------------
+    def has_table(self, table_name: str) -> Tuple[Status, bool]:
+        with self._lock:
+            bad = self._need()
+            if bad:
+                return bad, False
+            replies = self._call_all("has_table", table_name)
+            st = self._first_failure(replies)
+            return st, st.OK() and all(r[2] for r in replies)
+
+    def create_table(self, param: Dict[str, Any]) -> Status:
+        with self._lock:
+            bad = self._need()
+            if bad:
+                return bad
+            st = self._first_failure(self._call_all("create_table", param))
+            if st.OK():
+                self._metric[param["table_name"]] = int(param.get("metric_type", MetricType.L2))
+                self._rows[param["table_name"]] = [0] * len(self._workers)
+            return st
+
+    def create_index(self, table_name: str, index: Optional[Dict[str, Any]] = None, timeout: int = -1) -> Status:
+        with self._lock:
+            return self._need() or self._first_failure(self._call_all("create_index", table_name, index))
+
+    def delete_table(self, table_name: str) -> Status:
+        with self._lock:
+            bad = self._need()
+            if bad:
+                return bad
+            st = self._first_failure(self._call_all("delete_table", table_name))
+            self._metric.pop(table_name, None)
+            self._rows.pop(table_name, None)
+            return st
+
+    drop_table = delete_table
+
+    def get_table_row_count(self, table_name: str) -> Tuple[Status, int]:
+        with self._lock:
+            bad = self._need()
+            if bad:
+                return bad, 0
+            replies = self._call_all("get_table_row_count", table_name)
+            st = self._first_failure(replies)
+            return st, sum(int(r[2]) for r in replies) if st.OK() else 0
+
+    def _table_state(self, table_name: str) -> Optional[Status]:
+        """Metric and per-shard row counts of a table this client did not create (preloaded)."""
+        if table_name in self._metric:
+            return None
+        replies = self._call_all("describe_table", table_name)
+        st = self._first_failure(replies)
+        if not st.OK():
+            return st
+        self._metric[table_name] = int(replies[0][2]["metric_type"])
+        self._rows[table_name] = [int(r[2]["row_count"]) for r in replies]
+        return None
+
+    # -- append ----------------------------------------------------------------------------
+    def insert(self, table_name: str, records: Sequence[Sequence[float]], ids: Optional[Sequence[int]] = None,
+               timeout: int = -1) -> Tuple[Status, List[int]]:
+        with self._lock:
+            bad = self._need() or self._table_state(table_name)
+            if bad:
+                return bad, []
+            rows = np.asarray(records, dtype=np.float32)
+            if rows.ndim != 2:
+                return Status(_lib.EINVAL, "records must be a list of equal-length vectors"), []
+            counts = self._rows[table_name]
+            if ids is None:
+                base = sum(counts)
+                ids = list(range(base, base + rows.shape[0]))
+            ids = np.asarray(ids, dtype=np.int64)
+            if ids.shape[0] != rows.shape[0]:
+                return Status(_lib.EINVAL, "records and ids differ in length"), []
+            # fill the least-filled shards first, level after that
+            n, w = rows.shape[0], len(self._workers)
+            target = (sum(counts) + n + w - 1) // w
+            take = [0] * w
+            left = n
+            for s in sorted(range(w), key=lambda i: counts[i]):
+                t = max(0, min(left, target - counts[s]))
+                take[s] = t
+                left -= t
+            take[min(range(w), key=lambda i: counts[i] + take[i])] += left
+            pos, sent = 0, []
+            for s in range(w):
+                if take[s]:
+                    self._workers[s][1].send(("insert", (table_name, rows[pos:pos + take[s]], ids[pos:pos + take[s]]), {}))
+                    sent.append(s)
+                    pos += take[s]
+            st = Status()
+            for s in sent:
+                r = self._workers[s][1].recv()
+                if r[0] != 0:
+                    st = Status(r[0], r[1])
+                else:
+                    counts[s] += take[s]
+            return st, [int(i) for i in ids] if st.OK() else []
+
+    add_vectors = insert
+
+    # -- search ----------------------------------------------------------------------------
+    def search_vectors(self, table_name: str, top_k: int, nprobe: int = 0,
+                       query_records: Optional[Sequence[Sequence[float]]] = None,
+                       query_ranges=None) -> Tuple[Status, List[List[QueryResult]]]:
+        with self._lock:
+            bad = self._need() or self._table_state(table_name)
+            if bad:
+                return bad, []
+            q = np.asarray(query_records, dtype=np.float32)
+            if q.ndim != 2:
+                return Status(_lib.EINVAL, "query_records must be a list of equal-length vectors"), []
+            k = int(top_k)
+            replies = self._call_all("search_arrays", table_name, q, k)
+            st = self._first_failure(replies)
+            if not st.OK():
+                return st, []
+            l2 = self._metric[table_name] == int(MetricType.L2)
+            results = []
+            for qi in range(q.shape[0]):
+                ids = np.concatenate([r[2][qi, :int(r[4][qi])] for r in replies])
+                sc = np.concatenate([r[3][qi, :int(r[4][qi])] for r in replies])
+                order = np.lexsort((ids, sc if l2 else -sc))[:k]
+                results.append([QueryResult(int(ids[j]), float(sc[j])) for j in order])
+            return Status(), results
+
+    search = search_vectors
+
+    # -- snapshots -------------------------------------------------------------------------
+    def snapshot(self, table_name: str) -> Status:
+        """Every worker writes its shard under <primary_path>/shard<i>/ (and preloads it from there)."""
+        with self._lock:
+            return self._need() or self._first_failure(self._call_all("snapshot", table_name))
+
+    def preload_table(self, table_name: str, timeout: Optional[int] = None) -> Status:
+        with self._lock:
+            return self._need() or self._first_failure(self._call_all("preload_table", table_name))
