@@ -77,10 +77,20 @@ class ClusterMilvus:
         self._rows: Dict[str, List[int]] = {}                # rows per shard, for least-filled placement
 
     # -- plumbing ---------------------------------------------------------------------------
+    @staticmethod
+    def _recv(pipe) -> tuple:
+        try:
+            return pipe.recv()
+        except (EOFError, OSError) as exc:          # the worker process is gone
+            return (_lib.ESTATE, "engine worker not reachable: %s" % type(exc).__name__, None, None, None)
+
     def _call_all(self, method: str, *args, **kwargs) -> List[tuple]:
         for _, pipe in self._workers:
-            pipe.send((method, args, kwargs))
-        return [pipe.recv() for _, pipe in self._workers]
+            try:
+                pipe.send((method, args, kwargs))
+            except (OSError, ValueError):
+                pass                                # reported by the failing receive below
+        return [self._recv(pipe) for _, pipe in self._workers]
 
     @staticmethod
     def _first_failure(replies: List[tuple]) -> Status:
@@ -106,7 +116,7 @@ class ClusterMilvus:
                 proc.start()
                 child.close()
                 self._workers.append((proc, parent))
-            replies = [pipe.recv() for _, pipe in self._workers]
+            replies = [self._recv(pipe) for _, pipe in self._workers]
             st = self._first_failure(replies)
             if not st.OK():
                 self._stop()
@@ -232,7 +242,7 @@ class ClusterMilvus:
                     pos += take[s]
             st = Status()
             for s in sent:
-                r = self._workers[s][1].recv()
+                r = self._recv(self._workers[s][1])
                 if r[0] != 0:
                     st = Status(r[0], r[1])
                 else:
