@@ -834,7 +834,8 @@ struct Gemm32sParams {
     int          qstride;        // halfs per query row (multiple of 8)
     int          ldx;
     int          l2;
-    long long    ntiles;         // 256-row tiles
+    long long    ntiles;         // 256-row tiles visited: tile t * tile_stride, t < ntiles
+    long long    tile_stride;
     float*       cand_s;
     long long*   cand_t;
     int*         cnt;
@@ -915,7 +916,7 @@ gemm32s_kernel(Gemm32sParams p) {
     long long f_left = total;
     auto fetch = [&](int u) {
         const bool live = f_left > 0;
-        const long long row0 = f_tile * SB_M;
+        const long long row0 = f_tile * p.tile_stride * SB_M;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             long long r = row0 + arow[i];
@@ -999,7 +1000,7 @@ gemm32s_kernel(Gemm32sParams p) {
             if (++c_ks == nks) {
                 c_ks = 0;
                 // padded stages beyond the last tile multiply zeros and never reach this point
-                const long long row0 = c_tile * SB_M;
+                const long long row0 = c_tile * p.tile_stride * SB_M;
                 c_tile += gridDim.x;
                 const long long left = p.n - row0;
                 const int nloc = left < SB_M ? (int)left : SB_M;
@@ -1066,12 +1067,15 @@ static hipError_t launch_gemm32s_mode(const Gemm32sParams& p, int nq, int n_cu, 
 // Full pass over a table with the kernel above.  fp32 tables: qhi/qlo are bf16 (launch_split_query16,
 // stride qstride).  16-bit tables: qhi/qlo in the table's type, `split` says whether qlo is used.
 hipError_t launch_gemm32s(const TableView& t, const unsigned short* qhi, const unsigned short* qlo, int qstride,
-                          int split, int nq, int dpad, const float* thr, float* cand_s, long long* cand_t,
+                          int split, int nq, int dpad, const float* thr, long long tile_stride,
+                          float* cand_s, long long* cand_t,
                           int* cnt, int* lost, int cap, int n_cu, hipStream_t st) {
     Gemm32sParams p;
     p.X = t.rows; p.n2 = t.n2; p.Qhi = qhi; p.Qlo = qlo; p.thr = thr; p.n = t.n; p.nq = nq;
     p.dpad = dpad; p.qstride = qstride; p.ldx = t.dt == VDB_F32 ? t.m * 4 : t.m * 8; p.l2 = t.metric == VDB_METRIC_L2 ? 1 : 0;
-    p.ntiles = (t.n + SB_M - 1) / SB_M;
+    // every tile_stride-th 256-row tile (1 = the full pass; larger = a strided sample of the rows)
+    p.tile_stride = tile_stride < 1 ? 1 : tile_stride;
+    p.ntiles = ((t.n + SB_M - 1) / SB_M + p.tile_stride - 1) / p.tile_stride;
     p.cand_s = cand_s; p.cand_t = cand_t; p.cnt = cnt; p.lost = lost; p.cap = cap;
     if (t.dt == VDB_F32) return launch_gemm32s_mode<VDB_BF16, 0>(p, nq, n_cu, st);
     if (t.dt == VDB_BF16) return split ? launch_gemm32s_mode<VDB_BF16, 1>(p, nq, n_cu, st) : launch_gemm32s_mode<VDB_BF16, 2>(p, nq, n_cu, st);
@@ -1108,7 +1112,7 @@ hipError_t launch_gemm16_thresh(const TableView& t, const unsigned short* qhi, c
     // wide-tile kernel; otherwise the 128 x 128 tile kernel (unsplit) or the streaming kernel (split).
     const bool full = tile0 == 0 && tile_stride == 1 && ntiles == (t.n + HB_M - 1) / HB_M;
     if (!dense && full && ((g_gemm16_variant == 0 && split && nq <= 64) || g_gemm16_variant == 13))
-        return launch_gemm32s(t, qhi, qlo, dpad, split, nq, dpad, thr, cand_s, cand_t, cnt, lost, cap, n_cu, st);
+        return launch_gemm32s(t, qhi, qlo, dpad, split, nq, dpad, thr, 1, cand_s, cand_t, cnt, lost, cap, n_cu, st);
     if (!dense && full && nq > HB_N && (g_gemm16_variant == 0 || g_gemm16_variant == 12)) {
         Gemm16Params w = p;
         w.ntiles = (t.n + WB_M - 1) / WB_M;

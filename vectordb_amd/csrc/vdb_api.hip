@@ -382,7 +382,8 @@ static int search_gemm_path(const TableView& tv, const SelGeom& g, int dpad, int
             // strided sample of `tiles` row tiles under the current threshold -> next threshold
             const long long stride = ntiles / tiles;
             VDB_HIP(hipMemsetAsync(cnt, 0, (size_t)nqc * 8, st));
-            VDB_HIP(gemm(tv, tau, stride, ntiles / stride, 0));
+            if (s32) VDB_HIP(launch_gemm32s(tv, qhi, qlo, qstride, 1, nqi, dpad, tau, stride, cs, ct, cnt, lost, GEMM_CAP, G.n_cu, st));
+            else VDB_HIP(gemm(tv, tau, stride, ntiles / stride, 0));
             VDB_HIP(launch_kth_threshold(cs, GEMM_CAP, cnt, 0, GEMM_CAP, K, tau, spare, nqi, st));
             std::swap(tau, spare);
         }
@@ -390,7 +391,7 @@ static int search_gemm_path(const TableView& tv, const SelGeom& g, int dpad, int
         VDB_HIP(hipMemsetAsync(cnt, 0, (size_t)nqc * 8, st));
         ProfScope prof;
         if ((rc = prof.begin(st))) return rc;
-        if (s32) VDB_HIP(launch_gemm32s(tv, qhi, qlo, qstride, 1, nqi, dpad, tau, cs, ct, cnt, lost, GEMM_CAP, G.n_cu, st));
+        if (s32) VDB_HIP(launch_gemm32s(tv, qhi, qlo, qstride, 1, nqi, dpad, tau, 1, cs, ct, cnt, lost, GEMM_CAP, G.n_cu, st));
         else VDB_HIP(gemm(tv, tau, 1, ntiles, 0));
         if ((rc = prof.end(st))) return rc;
         VDB_HIP(launch_finalize_flat(tv, qprep, qinfo, nqi, dpad, g, k, cs, ct, cnt, GEMM_CAP, tau, lost, bad, fb,

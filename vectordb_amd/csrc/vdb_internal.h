@@ -100,7 +100,8 @@ hipError_t launch_gemm16_thresh(const TableView& t, const unsigned short* qhi, c
                                 int n_cu, hipStream_t st);
 void set_gemm16_variant(int v);
 hipError_t launch_gemm32s(const TableView& t, const unsigned short* qhi, const unsigned short* qlo, int qstride,
-                          int split, int nq, int dpad, const float* thr, float* cand_s, long long* cand_t,
+                          int split, int nq, int dpad, const float* thr, long long tile_stride,
+                          float* cand_s, long long* cand_t,
                           int* cnt, int* lost, int cap, int n_cu, hipStream_t st);
 hipError_t launch_split_query16(int dt, const float* qprep, int nq, int dpad, int stride_out, unsigned short* hi,
                                 unsigned short* lo, int* bad, hipStream_t st);
