@@ -870,6 +870,8 @@ gemm32s_kernel(Gemm32sParams p) {
     constexpr int NA = MODE == 0 ? 4 : 2;          // 16-byte row chunks staged per thread and k-step
     constexpr int CPR = MODE == 0 ? 8 : 4;         // 16-byte chunks per tile row and k-step
     constexpr int EPC = MODE == 0 ? 4 : 8;         // elements per chunk
+    constexpr int RD = NB == 4 ? 2 : 4;            // k-steps of operands in registers (narrow tiles have
+                                                   // little MFMA time per step to cover the load latency)
     constexpr int TN = 32 * NB;                    // queries per tile
     constexpr int NI = NB == 4 ? 2 : 1;            // 32-query blocks per wave
     constexpr int MI = NB == 1 ? 1 : 2;            // 32-row blocks per wave
@@ -907,10 +909,10 @@ gemm32s_kernel(Gemm32sParams p) {
 
     const long long my_tiles = (p.ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
     const long long total = my_tiles * nks;
-    const long long padded = (total + 1) / 2 * 2;
+    const long long padded = (total + RD - 1) / RD * RD;
 
-    u32x4g ra[2][NA];                              // raw 16 bytes: 4 fp32 or 8 16-bit values
-    u32x4g rh[2], rl[2];
+    u32x4g ra[RD][NA];                             // raw 16 bytes: 4 fp32 or 8 16-bit values
+    u32x4g rh[RD], rl[RD];
     long long f_tile = blockIdx.x;
     int f_ks = 0;
     long long f_left = total;
@@ -936,20 +938,20 @@ gemm32s_kernel(Gemm32sParams p) {
         --f_left;
         if (++f_ks == nks) { f_ks = 0; f_tile += gridDim.x; }
     };
-    fetch(0);
-    fetch(1);
+#pragma unroll
+    for (int u = 0; u < RD; ++u) fetch(u);
 
     f32x16 acc[MI][NI];
     long long c_tile = blockIdx.x;
     int c_ks = 0;
-    for (long long s0 = 0; s0 < padded; s0 += 2) {
+    for (long long s0 = 0; s0 < padded; s0 += RD) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            // every wave finished reading buffer u (two k-steps ago) before it passed the last barrier
-            unsigned short* Ahu = Ah + u * (SB_M * SB_LD);
-            unsigned short* Alu = Al + u * (SB_M * SB_LD);
-            unsigned short* Bhu = Bh + u * (TN * SB_LD);
-            unsigned short* Blu = Bl + u * (TN * SB_LD);
+        for (int u = 0; u < RD; ++u) {
+            // LDS buffer u & 1: every wave finished reading it (two k-steps ago) before it passed the last barrier
+            unsigned short* Ahu = Ah + (u & 1) * (SB_M * SB_LD);
+            unsigned short* Alu = Al + (u & 1) * (SB_M * SB_LD);
+            unsigned short* Bhu = Bh + (u & 1) * (TN * SB_LD);
+            unsigned short* Blu = Bl + (u & 1) * (TN * SB_LD);
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 if constexpr (MODE == 0) {
