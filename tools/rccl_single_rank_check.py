@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Runs the sharded search path through the real RCCL backend with a world of one rank (all a
+one-GPU box allows): process-group creation with a device id, all_gather_into_tensor on the uint8
+record under side streams, the merge, and teardown -- the calls bench.py makes with N ranks."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vectordb_amd import _lib  # noqa: E402
+from vectordb_amd.engine import Engine  # noqa: E402
+from vectordb_amd.sharded import ShardedSearcher, gpu_backend  # noqa: E402
+
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29577")
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+eng = Engine(0)
+eng.create_table("r", 96, _lib.METRIC_COSINE, _lib.F32)
+eng.insert_synthetic("r", 200_000, 0, 0)
+q = torch.empty((8, 96), dtype=torch.float32, device=dev)
+eng.synth_fill_dev(q.data_ptr(), 8, 96, 1, 0, torch.cuda.current_stream().cuda_stream)
+ls, mg = gpu_backend(eng, "r", 1, 10, _lib.METRIC_COSINE)
+streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+searchers = [ShardedSearcher(1, 10, dev, ls, mg) for _ in range(3)]
+for s in searchers:
+    s.world = 1
+torch.cuda.synchronize()
+outs = []
+for i in range(8):
+    with torch.cuda.stream(streams[i % 3]):
+        s = searchers[i % 3]
+        s.local_search(q[i:i + 1], s.rec_views)
+        dist.all_gather_into_tensor(s.gathered, s.rec)              # the collective bench.py issues for N > 1
+        s.merge(s.gathered, 1, s.out_views)
+        outs.append((s.out_views.ids.clone(), s.out_views.scores.clone()))
+torch.cuda.synchronize()
+dist.barrier()
+ids, sc, cnt = eng.search("r", q.cpu().numpy(), 10)
+ok = all(np.array_equal(o[0].cpu().numpy()[0], ids[i]) and np.array_equal(o[1].cpu().numpy()[0], sc[i]) for i, o in enumerate(outs))
+dist.destroy_process_group()
+print("RCCL single-rank path:", "ok" if ok else "MISMATCH")
+sys.exit(0 if ok else 1)
