@@ -299,8 +299,9 @@ constexpr int HB_M = 128, HB_N = 128, HB_K = 64, HB_LD = HB_K + 8;   // LDS row 
 struct Gemm16Params {
     const unsigned short* X;     // [n][ldx] 16-bit elements
     const float* n2;
-    const unsigned short* Qhi;   // [nq][dpad]
-    const unsigned short* Qlo;   // [nq][dpad] (SPLIT only)
+    const unsigned short* Qhi;   // [nq][ldq]
+    const unsigned short* Qlo;   // [nq][ldq] (SPLIT only)
+    int          ldq;            // halfs per query row (>= dpad, zero padded)
     const float* thr;
     long long    n;
     int          nq;
@@ -345,8 +346,8 @@ gemm16_thresh_kernel(Gemm16Params p) {
     for (int i = 0; i < 4; ++i) {
         int q = qt * HB_N + srow[i];
         if (q > p.nq - 1) q = p.nq - 1;
-        qh[i] = p.Qhi + (size_t)q * p.dpad;
-        ql[i] = SPLIT ? p.Qlo + (size_t)q * p.dpad : nullptr;
+        qh[i] = p.Qhi + (size_t)q * p.ldq;
+        ql[i] = SPLIT ? p.Qlo + (size_t)q * p.ldq : nullptr;
     }
     float thr[2];
 #pragma unroll
@@ -433,9 +434,11 @@ gemm16_thresh_kernel(Gemm16Params p) {
             }
             if (++c_ks == nks) {
                 c_ks = 0;
-                // padded stages beyond the last tile multiply zeros and never reach this point
+                // padded stages beyond the last tile multiply zeros; with few k-steps per tile they
+                // complete a tile that does not exist
                 const long long row0 = (p.tile0 + c_tile * p.tile_stride) * HB_M;
                 c_tile += gridDim.x;
+                if (row0 >= p.n) continue;
                 const long long left = p.n - row0;
                 const int nloc = left < HB_M ? (int)left : HB_M;       // rows of this tile that exist
                 const int q0 = qt * HB_N + wn * 64 + li;
@@ -444,11 +447,11 @@ gemm16_thresh_kernel(Gemm16Params p) {
                     const int lr0 = wm * 64 + mi * 32 + 4 * lh;         // this lane's rows: lr0 + (r&3) + 8*(r>>2)
                     float rn2[16];
                     if (p.l2) {
-                        const float* n2p = p.n2 + row0 + lr0;
+                        const float* n2p = p.n2 + row0;                 // row0 < n here
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            const int o = (r & 3) + 8 * (r >> 2);
-                            rn2[r] = n2p[lr0 + o < nloc ? o : 0];
+                            const int o = lr0 + (r & 3) + 8 * (r >> 2);
+                            rn2[r] = n2p[o < nloc ? o : 0];
                         }
                     }
                     if constexpr (DENSE) {
@@ -518,8 +521,8 @@ gemm16_stream_kernel(Gemm16Params p) {
     for (int i = 0; i < 4; ++i) {
         int q = qt * HB_N + srow[i];
         if (q > p.nq - 1) q = p.nq - 1;
-        qh[i] = p.Qhi + (size_t)q * p.dpad;
-        ql[i] = SPLIT ? p.Qlo + (size_t)q * p.dpad : nullptr;
+        qh[i] = p.Qhi + (size_t)q * p.ldq;
+        ql[i] = SPLIT ? p.Qlo + (size_t)q * p.ldq : nullptr;
     }
     float thr[4];
 #pragma unroll
@@ -667,8 +670,8 @@ gemm16_wide_kernel(Gemm16Params p) {
     for (int i = 0; i < 2; ++i) {
         int q = qt * WB_N + srow[i];
         if (q > p.nq - 1) q = p.nq - 1;
-        qh[i] = p.Qhi + (size_t)q * p.dpad;
-        ql[i] = SPLIT ? p.Qlo + (size_t)q * p.dpad : nullptr;
+        qh[i] = p.Qhi + (size_t)q * p.ldq;
+        ql[i] = SPLIT ? p.Qlo + (size_t)q * p.ldq : nullptr;
     }
     float thr[2];
 #pragma unroll
@@ -753,9 +756,11 @@ gemm16_wide_kernel(Gemm16Params p) {
             }
             if (++c_ks == nks) {
                 c_ks = 0;
-                // padded stages beyond the last tile multiply zeros and never reach this point
+                // padded stages beyond the last tile multiply zeros; with one k-step per tile they
+                // complete a tile that does not exist
                 const long long row0 = c_tile * WB_M;
                 c_tile += gridDim.x;
+                if (row0 >= p.n) continue;
                 const long long left = p.n - row0;
                 const int nloc = left < WB_M ? (int)left : WB_M;
                 const int q0 = qt * WB_N + wn * 64 + li;
@@ -764,11 +769,11 @@ gemm16_wide_kernel(Gemm16Params p) {
                     const int lr0 = wm * 128 + mi * 32 + 4 * lh;     // this lane's rows: lr0 + (r&3) + 8*(r>>2)
                     float rn2[16];
                     if (p.l2) {
-                        const float* n2p = p.n2 + row0 + lr0;
+                        const float* n2p = p.n2 + row0;                 // row0 < n here
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            const int o = (r & 3) + 8 * (r >> 2);
-                            rn2[r] = n2p[lr0 + o < nloc ? o : 0];
+                            const int o = lr0 + (r & 3) + 8 * (r >> 2);
+                            rn2[r] = n2p[o < nloc ? o : 0];
                         }
                     }
 #pragma unroll
@@ -818,20 +823,20 @@ static hipError_t launch_wide(const Gemm16Params& p, int nq, int n_cu, hipStream
 // xh*qh + xh*ql + xl*qh, leaving a relative error of 3 * 2^-16 per term against 16 x the fp32 MFMA
 // rate / 3.  A workgroup of 8 waves owns 256 rows x 128 queries (64 x 64 per wave), LDS tiles are
 // double-buffered, two k-steps of operands ride in registers across tile boundaries.
-constexpr int SB_M = 256, SB_K = 32, SB_LD = SB_K + 8;     // LDS row = 40 halfs = 80 bytes
+constexpr int SB_K = 32, SB_LD = SB_K + 8;     // LDS row = 40 halfs = 80 bytes
 typedef __bf16 bf16x2g __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2g __attribute__((ext_vector_type(2)));
 
 struct Gemm32sParams {
     const void*  X;              // [n][ldx] rows: fp32 (MODE 0) or 16-bit (MODE 1, 2)
     const float* n2;
-    const unsigned short* Qhi;   // [nq][qstride] bf16, zero padded to a multiple of 8
+    const unsigned short* Qhi;   // [nq][qstride], zero padded
     const unsigned short* Qlo;
     const float* thr;
     long long    n;
     int          nq;
     int          dpad;           // elements per row (multiple of 4 for fp32 rows, of 8 for 16-bit rows)
-    int          qstride;        // halfs per query row (multiple of 8)
+    int          qstride;        // halfs per query row: a multiple of 32 (whole k-steps), >= dpad
     int          ldx;
     int          l2;
     long long    ntiles;         // 256-row tiles visited: tile t * tile_stride, t < ntiles
@@ -858,48 +863,72 @@ __device__ __forceinline__ void split4_bf16(const f32x4& x, u32x2g& hi, u32x2g& 
     lo[0] = (unsigned int)l[0] | ((unsigned int)l[1] << 16); lo[1] = (unsigned int)l[2] | ((unsigned int)l[3] << 16);
 }
 
-// NB = 32-query blocks per workgroup tile: 4 (128 queries, 64 x 64 per wave), 2 (64 queries, 64 x 32
-// per wave) or 1 (32 queries, 32 x 32 per wave; small batches then cost little more than reading
-// the rows once).  The tile is 256 rows in every case.
+// NB = 32-query blocks per workgroup tile: 8 (256 queries, 64 x 128 per wave; single-product modes
+// only, where the pass is bound by re-reading the rows once per query tile), 4 (128 queries, 64 x 64
+// per wave), 2 (64 queries, 64 x 32 per wave) or 1 (32 queries, 32 x 32 per wave; small batches then
+// cost little more than reading the rows once).  The tile is 256 rows in every case.
 // MODE 0: fp32 rows split into bf16 hi + lo, split query, three products per term;
-// MODE 1: 16-bit rows as stored, split query, two products; MODE 2: 16-bit rows, query hi only.
+// MODE 1: 16-bit rows as stored, split query, two products; MODE 2: 16-bit rows, query hi only;
+// MODE 3: fp32 rows rounded to bf16 on the way to LDS, query hi only, one product per term (relative
+// error 2^-8 of ||x|| ||q||: the re-scored band is wider, the pass three times cheaper).
 // DT is the 16-bit type the MFMA multiplies in (bf16 for MODE 0, the table's type otherwise).
-template <int NB, int DT, int MODE>
-__global__ void __launch_bounds__(512, 1)
+// 4 fp32 -> 4 bf16 (round to nearest even), packed in 8 bytes
+__device__ __forceinline__ u32x2g round4_bf16(const f32x4& x) {
+    unsigned short h[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) h[e] = __builtin_bit_cast(unsigned short, (__bf16)x[e]);
+    u32x2g r;
+    r[0] = (unsigned int)h[0] | ((unsigned int)h[1] << 16);
+    r[1] = (unsigned int)h[2] | ((unsigned int)h[3] << 16);
+    return r;
+}
+
+template <int NB, int DT, int MODE, int NT>
+__global__ void __launch_bounds__(NT, NT == 256 ? 2 : 1)
 gemm32s_kernel(Gemm32sParams p) {
-    constexpr int NA = MODE == 0 ? 4 : 2;          // 16-byte row chunks staged per thread and k-step
-    constexpr int CPR = MODE == 0 ? 8 : 4;         // 16-byte chunks per tile row and k-step
-    constexpr int EPC = MODE == 0 ? 4 : 8;         // elements per chunk
-    constexpr int RD = NB == 4 ? 2 : 4;            // k-steps of operands in registers (narrow tiles have
+    constexpr int TM = NT / 2;                     // rows per tile: 256 (8 waves) or 128 (4 waves, two workgroups per CU)
+    constexpr bool F32ROWS = MODE == 0 || MODE == 3;
+    constexpr bool ALO = MODE == 0;                // rows have a lo part
+    constexpr bool BLO = MODE == 0 || MODE == 1;   // queries have a lo part
+    constexpr int NA = F32ROWS ? 4 : 2;            // 16-byte row chunks staged per thread and k-step
+    constexpr int CPR = F32ROWS ? 8 : 4;           // 16-byte chunks per tile row and k-step
+    constexpr int EPC = F32ROWS ? 4 : 8;           // elements per chunk
+    constexpr int RD = NB >= 4 ? 2 : 4;            // k-steps of operands in registers (narrow tiles have
                                                    // little MFMA time per step to cover the load latency)
     constexpr int TN = 32 * NB;                    // queries per tile
-    constexpr int NI = NB == 4 ? 2 : 1;            // 32-query blocks per wave
+    constexpr int NI = NB == 8 ? 4 : NB == 4 ? 2 : 1;   // 32-query blocks per wave
+    constexpr int QCH = TN * 4 > NT ? TN * 4 / NT : 1;   // 16-byte query chunks staged per thread and k-step
+    constexpr int RDB = QCH >= 4 ? 1 : RD;         // k-steps of query chunks in registers (they come from L2)
     constexpr int MI = NB == 1 ? 1 : 2;            // 32-row blocks per wave
     constexpr int WN = NB / NI;                    // waves across the queries
     extern __shared__ __attribute__((aligned(16))) unsigned short ssm[];
-    unsigned short* Ah = ssm;                                  // [2][SB_M * SB_LD]
-    unsigned short* Al = Ah + 2 * SB_M * SB_LD;                // MODE 0 only
-    unsigned short* Bh = Al + (MODE == 0 ? 2 * SB_M * SB_LD : 0);   // [2][TN * SB_LD]
-    unsigned short* Bl = Bh + 2 * TN * SB_LD;                  // MODE 0, 1
+    unsigned short* Ah = ssm;                                  // [2][TM * SB_LD]
+    unsigned short* Al = Ah + 2 * TM * SB_LD;                  // rows with a lo part only
+    unsigned short* Bh = Al + (ALO ? 2 * TM * SB_LD : 0);      // [2][TN * SB_LD]
+    unsigned short* Bl = Bh + 2 * TN * SB_LD;                  // queries with a lo part only
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
     const int qt = blockIdx.y;
     const int nks = (p.dpad + SB_K - 1) / SB_K;
     const int dch = p.dpad / EPC;                  // 16-byte chunks per row
-    const int q8 = p.qstride >> 3;                 // 8-half chunks per query row
 
-    // staging: row chunks f = tid + 512 * i (i < NA): tile row f / CPR, chunk f % CPR;
-    //          query chunk tid: tile query tid / 4, 8-half chunk tid % 4
+    // staging: row chunks f = tid + NT * i (i < NA): tile row f / CPR, chunk f % CPR;
+    //          query chunks g = tid + NT * j (j < QCH): tile query g / 4, 8-half chunk g % 4
     int arow[NA], ac[NA];
 #pragma unroll
-    for (int i = 0; i < NA; ++i) { const int f = tid + 512 * i; arow[i] = f / CPR; ac[i] = f % CPR; }
-    const int brow = tid >> 2, bc = tid & 3;
+    for (int i = 0; i < NA; ++i) { const int f = tid + NT * i; arow[i] = f / CPR; ac[i] = f % CPR; }
+    const int brow = tid >> 2, bc = tid & 3;       // chunk j: tile query brow + (NT / 4) * j
     const bool bstage = tid < TN * 4;              // threads that stage a query chunk
-    int qb = qt * TN + (bstage ? brow : 0);
-    if (qb > p.nq - 1) qb = p.nq - 1;
-    const unsigned short* qh = p.Qhi + (size_t)qb * p.qstride;
-    const unsigned short* ql = p.Qlo + (size_t)qb * p.qstride;
+    const unsigned short* qh[QCH];
+    const unsigned short* ql[QCH];
+#pragma unroll
+    for (int j = 0; j < QCH; ++j) {
+        int qb = qt * TN + (bstage ? brow + (NT / 4) * j : 0);
+        if (qb > p.nq - 1) qb = p.nq - 1;
+        qh[j] = p.Qhi + (size_t)qb * p.qstride;
+        ql[j] = p.Qlo + (size_t)qb * p.qstride;
+    }
     float thr[NI];
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
@@ -912,62 +941,103 @@ gemm32s_kernel(Gemm32sParams p) {
     const long long padded = (total + RD - 1) / RD * RD;
 
     u32x4g ra[RD][NA];                             // raw 16 bytes: 4 fp32 or 8 16-bit values
-    u32x4g rh[RD], rl[RD];
+    u32x4g rh[RDB][QCH], rl[RDB][QCH];
     long long f_tile = blockIdx.x;
     int f_ks = 0;
-    long long f_left = total;
+    // No load below selects between two base addresses: the compiler turns such a select into
+    // branches whose join waits for every outstanding load (s_waitcnt vmcnt(0)), which serialises
+    // the prefetch.  Padded stages beyond the last tile re-read the table's last row (their tile is
+    // never written out), chunks past the row's end re-read the row's first bytes (the query
+    // operand, padded with zeros to a multiple of the k-step, is zero there).
     auto fetch = [&](int u) {
-        const bool live = f_left > 0;
-        const long long row0 = f_tile * p.tile_stride * SB_M;
+        const long long row0 = f_tile * p.tile_stride * TM;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             long long r = row0 + arow[i];
             if (r > p.n - 1) r = p.n - 1;
             const int ch = f_ks * CPR + ac[i];
-            // past the row's end the row operand re-reads the row's first bytes: the query operand is zero there
-            const char* xa = live ? (const char*)p.X + ((size_t)r * p.ldx + (ch < dch ? ch * EPC : 0)) * (MODE == 0 ? 4 : 2)
-                                  : (const char*)g_zero16;
-            ra[u][i] = __builtin_nontemporal_load((const u32x4g*)xa);
+            const char* xa = (const char*)p.X + ((size_t)r * p.ldx + (ch < dch ? ch * EPC : 0)) * (F32ROWS ? 4 : 2);
+            // rows stream once past a single query tile; several query tiles of one row range run
+            // on one XCD side by side and meet in its L2, so their loads leave the lines there
+            ra[u][i] = gridDim.y == 1 ? __builtin_nontemporal_load((const u32x4g*)xa) : *(const u32x4g*)xa;
         }
-        const int c8 = f_ks * (SB_K / 8) + bc;
-        const bool okq = live && c8 < q8;
-        if (NB == 4 || bstage) {
-            rh[u] = *(const u32x4g*)(okq ? qh + c8 * 8 : (const unsigned short*)g_zero16);
-            if (MODE != 2) rl[u] = *(const u32x4g*)(okq ? ql + c8 * 8 : (const unsigned short*)g_zero16);
-        }
-        --f_left;
         if (++f_ks == nks) { f_ks = 0; f_tile += gridDim.x; }
     };
+    // the query chunks of a k-step are the same for every tile: a cursor of their own, cycling over
+    // the k-steps
+    int b_ks = 0;
+    auto fetch_q = [&](int v) {
+        const int c8 = b_ks * (SB_K / 8) + bc;     // < qstride / 8: query rows are padded to whole k-steps
+        if (TN * 4 >= NT || bstage) {
 #pragma unroll
-    for (int u = 0; u < RD; ++u) fetch(u);
+            for (int j = 0; j < QCH; ++j) {
+                rh[v][j] = *(const u32x4g*)(qh[j] + c8 * 8);
+                if (BLO) rl[v][j] = *(const u32x4g*)(ql[j] + c8 * 8);
+            }
+        }
+        if (++b_ks == nks) b_ks = 0;
+    };
+    // Issued in the order of the loop below and kept in it (the scheduler would otherwise be free
+    // to reorder these independent loads): the loop's wait for a stage's operands is a counted
+    // s_waitcnt vmcnt(N), valid only if the younger stages' loads really are younger on every path
+    // into the loop; a prologue in another order degrades it to vmcnt(0), which drains the prefetch.
+#pragma unroll
+    for (int u = 0; u < RD; ++u) {
+        if (RDB == RD || u == RD - 1) fetch_q(RDB == 1 ? 0 : u);
+        fetch(u);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 
+    // stage(w, b): operands of register set w go to LDS buffer b (fp32 rows converted on the way),
+    // then the set is refilled with the operands RD k-steps ahead
+    auto stage = [&](int w, int b) {
+        unsigned short* Ahw = Ah + b * (TM * SB_LD);
+        unsigned short* Alw = Al + b * (TM * SB_LD);
+        unsigned short* Bhw = Bh + b * (TN * SB_LD);
+        unsigned short* Blw = Bl + b * (TN * SB_LD);
+        const int wb = RDB == 1 ? 0 : w;            // query register set
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            if constexpr (MODE == 0) {
+                u32x2g h2, l2;
+                split4_bf16(__builtin_bit_cast(f32x4, ra[w][i]), h2, l2);
+                *(u32x2g*)&Ahw[arow[i] * SB_LD + ac[i] * 4] = h2;
+                *(u32x2g*)&Alw[arow[i] * SB_LD + ac[i] * 4] = l2;
+            } else if constexpr (MODE == 3) {
+                *(u32x2g*)&Ahw[arow[i] * SB_LD + ac[i] * 4] = round4_bf16(__builtin_bit_cast(f32x4, ra[w][i]));
+            } else {
+                *(u32x4g*)&Ahw[arow[i] * SB_LD + ac[i] * 8] = ra[w][i];
+            }
+        }
+        if (TN * 4 >= NT || bstage) {
+#pragma unroll
+            for (int j = 0; j < QCH; ++j) {
+                *(u32x4g*)&Bhw[(brow + (NT / 4) * j) * SB_LD + bc * 8] = rh[wb][j];
+                if (BLO) *(u32x4g*)&Blw[(brow + (NT / 4) * j) * SB_LD + bc * 8] = rl[wb][j];
+            }
+        }
+        // queries first: with one k-step of them in registers they are needed a stage before the
+        // rows issued next to them, and a counted wait covers everything older than what it waits for
+        fetch_q(wb);
+        fetch(w);
+    };
+    stage(0, 0);
+
+    // One barrier per k-step.  The operands of k-step t+1 are written to the other LDS buffer
+    // between the two halves of k-step t's MFMA work, not before the barrier: the two waves of a
+    // SIMD drift half a step apart, and one's conversions, LDS stores and load issue run under
+    // the other's MFMAs.  (Buffer (t+1)&1 was last read in k-step t-1, which every wave finished
+    // before the barrier of k-step t.)
     f32x16 acc[MI][NI];
     long long c_tile = blockIdx.x;
     int c_ks = 0;
     for (long long s0 = 0; s0 < padded; s0 += RD) {
 #pragma unroll
         for (int u = 0; u < RD; ++u) {
-            // LDS buffer u & 1: every wave finished reading it (two k-steps ago) before it passed the last barrier
-            unsigned short* Ahu = Ah + (u & 1) * (SB_M * SB_LD);
-            unsigned short* Alu = Al + (u & 1) * (SB_M * SB_LD);
-            unsigned short* Bhu = Bh + (u & 1) * (TN * SB_LD);
-            unsigned short* Blu = Bl + (u & 1) * (TN * SB_LD);
-#pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                if constexpr (MODE == 0) {
-                    u32x2g h2, l2;
-                    split4_bf16(__builtin_bit_cast(f32x4, ra[u][i]), h2, l2);
-                    *(u32x2g*)&Ahu[arow[i] * SB_LD + ac[i] * 4] = h2;
-                    *(u32x2g*)&Alu[arow[i] * SB_LD + ac[i] * 4] = l2;
-                } else {
-                    *(u32x4g*)&Ahu[arow[i] * SB_LD + ac[i] * 8] = ra[u][i];
-                }
-            }
-            if (NB == 4 || bstage) {
-                *(u32x4g*)&Bhu[brow * SB_LD + bc * 8] = rh[u];
-                if (MODE != 2) *(u32x4g*)&Blu[brow * SB_LD + bc * 8] = rl[u];
-            }
-            fetch(u);
+            const unsigned short* Ahu = Ah + (u & 1) * (TM * SB_LD);
+            const unsigned short* Alu = Al + (u & 1) * (TM * SB_LD);
+            const unsigned short* Bhu = Bh + (u & 1) * (TN * SB_LD);
+            const unsigned short* Blu = Bl + (u & 1) * (TN * SB_LD);
             __syncthreads();
             if (c_ks == 0) {
 #pragma unroll
@@ -979,44 +1049,47 @@ gemm32s_kernel(Gemm32sParams p) {
             }
 #pragma unroll
             for (int kk = 0; kk < SB_K / 16; ++kk) {
+                if (kk == SB_K / 32) stage((u + 1) % RD, (u + 1) & 1);
                 u32x4g ah[MI], al[MI], bh[NI], bl[NI];
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
                     ah[mi] = *(const u32x4g*)&Ahu[((wm * MI + mi) * 32 + li) * SB_LD + kk * 16 + lh * 8];
-                    if (MODE == 0) al[mi] = *(const u32x4g*)&Alu[((wm * MI + mi) * 32 + li) * SB_LD + kk * 16 + lh * 8];
+                    if (ALO) al[mi] = *(const u32x4g*)&Alu[((wm * MI + mi) * 32 + li) * SB_LD + kk * 16 + lh * 8];
                 }
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
                     bh[ni] = *(const u32x4g*)&Bhu[((wn * NI + ni) * 32 + li) * SB_LD + kk * 16 + lh * 8];
-                    if (MODE != 2) bl[ni] = *(const u32x4g*)&Blu[((wn * NI + ni) * 32 + li) * SB_LD + kk * 16 + lh * 8];
+                    if (BLO) bl[ni] = *(const u32x4g*)&Blu[((wn * NI + ni) * 32 + li) * SB_LD + kk * 16 + lh * 8];
                 }
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni) {
-                        if (MODE == 0) acc[mi][ni] = mfma16<DT>(al[mi], bh[ni], acc[mi][ni]);
-                        if (MODE != 2) acc[mi][ni] = mfma16<DT>(ah[mi], bl[ni], acc[mi][ni]);
+                        if (ALO) acc[mi][ni] = mfma16<DT>(al[mi], bh[ni], acc[mi][ni]);
+                        if (BLO) acc[mi][ni] = mfma16<DT>(ah[mi], bl[ni], acc[mi][ni]);
                         acc[mi][ni] = mfma16<DT>(ah[mi], bh[ni], acc[mi][ni]);
                     }
             }
             if (++c_ks == nks) {
                 c_ks = 0;
-                // padded stages beyond the last tile multiply zeros and never reach this point
-                const long long row0 = c_tile * p.tile_stride * SB_M;
+                // padded stages beyond the last tile: with few k-steps per tile they
+                // complete a tile that does not exist
+                const long long row0 = c_tile * p.tile_stride * TM;
                 c_tile += gridDim.x;
+                if (row0 >= p.n) continue;
                 const long long left = p.n - row0;
-                const int nloc = left < SB_M ? (int)left : SB_M;
+                const int nloc = left < TM ? (int)left : TM;
                 const int q0 = qt * TN + wn * NI * 32 + li;
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
                     const int lr0 = (wm * MI + mi) * 32 + 4 * lh;     // this lane's rows: lr0 + (r&3) + 8*(r>>2)
                     float rn2[16];
                     if (p.l2) {
-                        const float* n2p = p.n2 + row0 + lr0;
+                        const float* n2p = p.n2 + row0;                 // row0 < n here
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            const int o = (r & 3) + 8 * (r >> 2);
-                            rn2[r] = n2p[lr0 + o < nloc ? o : 0];
+                            const int o = lr0 + (r & 3) + 8 * (r >> 2);
+                            rn2[r] = n2p[o < nloc ? o : 0];
                         }
                     }
 #pragma unroll
@@ -1041,33 +1114,45 @@ gemm32s_kernel(Gemm32sParams p) {
     }
 }
 
-template <int NB, int DT, int MODE>
-static hipError_t launch_gemm32s_nb(const Gemm32sParams& p, int nq, int n_cu, hipStream_t st) {
-    const size_t lds = (size_t)2 * ((MODE == 0 ? 2 : 1) * SB_M + (MODE == 2 ? 1 : 2) * 32 * NB) * SB_LD * sizeof(unsigned short);
+template <int NB, int DT, int MODE, int NT>
+static hipError_t launch_gemm32s_nb(const Gemm32sParams& p0, int nq, int n_cu, hipStream_t st) {
+    constexpr int TM = NT / 2;
+    const size_t lds = (size_t)2 * ((MODE == 0 ? 2 : 1) * TM + (MODE == 0 || MODE == 1 ? 2 : 1) * 32 * NB) * SB_LD * sizeof(unsigned short);
     static bool allowed = false;
     if (!allowed) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm32s_kernel<NB, DT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm32s_kernel<NB, DT, MODE, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         allowed = true;
     }
+    Gemm32sParams p = p0;
+    // every tile_stride-th TM-row tile (1 = the full pass; larger = a strided sample of the rows)
+    p.ntiles = ((p.n + TM - 1) / TM + p.tile_stride - 1) / p.tile_stride;
     const int qtiles = (nq + 32 * NB - 1) / (32 * NB);
-    long long gx = (long long)n_cu / qtiles;                  // one workgroup per CU
+    long long gx = (long long)n_cu * (512 / NT) / qtiles;     // one workgroup of 8 waves or two of 4 per CU
     gx = gx / 8 * 8;                                          // query tiles of one row range share an XCD
     if (gx < 8) gx = 8;
     if (gx > p.ntiles) gx = p.ntiles;
-    hipLaunchKernelGGL((gemm32s_kernel<NB, DT, MODE>), dim3((unsigned)gx, (unsigned)qtiles), dim3(512), lds, st, p);
+    hipLaunchKernelGGL((gemm32s_kernel<NB, DT, MODE, NT>), dim3((unsigned)gx, (unsigned)qtiles), dim3(NT), lds, st, p);
     return hipGetLastError();
 }
 
+static int g_gemm32s_threads = 512;      // workgroup size of the 256-query tile: 256 (two workgroups per CU) or 512
+void set_gemm32s_threads(int v) { g_gemm32s_threads = v == 512 ? 512 : 256; }
+
 template <int DT, int MODE>
 static hipError_t launch_gemm32s_mode(const Gemm32sParams& p, int nq, int n_cu, hipStream_t st) {
-    if (nq <= 32) return launch_gemm32s_nb<1, DT, MODE>(p, nq, n_cu, st);
-    if (nq <= 64) return launch_gemm32s_nb<2, DT, MODE>(p, nq, n_cu, st);
-    return launch_gemm32s_nb<4, DT, MODE>(p, nq, n_cu, st);
+    if (nq <= 32) return launch_gemm32s_nb<1, DT, MODE, 512>(p, nq, n_cu, st);
+    if (nq <= 64) return launch_gemm32s_nb<2, DT, MODE, 512>(p, nq, n_cu, st);
+    if constexpr (MODE == 2 || MODE == 3) {
+        if (nq > 128) return g_gemm32s_threads == 256 ? launch_gemm32s_nb<8, DT, MODE, 256>(p, nq, n_cu, st)
+                                                      : launch_gemm32s_nb<8, DT, MODE, 512>(p, nq, n_cu, st);
+    }
+    return launch_gemm32s_nb<4, DT, MODE, 512>(p, nq, n_cu, st);
 }
 
 // Full pass over a table with the kernel above.  fp32 tables: qhi/qlo are bf16 (launch_split_query16,
-// stride qstride).  16-bit tables: qhi/qlo in the table's type, `split` says whether qlo is used.
+// stride qstride); `split` = rows and query as hi + lo (three products), else both rounded to bf16.
+// 16-bit tables: qhi/qlo in the table's type, `split` says whether qlo is used.
 hipError_t launch_gemm32s(const TableView& t, const unsigned short* qhi, const unsigned short* qlo, int qstride,
                           int split, int nq, int dpad, const float* thr, long long tile_stride,
                           float* cand_s, long long* cand_t,
@@ -1075,11 +1160,10 @@ hipError_t launch_gemm32s(const TableView& t, const unsigned short* qhi, const u
     Gemm32sParams p;
     p.X = t.rows; p.n2 = t.n2; p.Qhi = qhi; p.Qlo = qlo; p.thr = thr; p.n = t.n; p.nq = nq;
     p.dpad = dpad; p.qstride = qstride; p.ldx = t.dt == VDB_F32 ? t.m * 4 : t.m * 8; p.l2 = t.metric == VDB_METRIC_L2 ? 1 : 0;
-    // every tile_stride-th 256-row tile (1 = the full pass; larger = a strided sample of the rows)
     p.tile_stride = tile_stride < 1 ? 1 : tile_stride;
-    p.ntiles = ((t.n + SB_M - 1) / SB_M + p.tile_stride - 1) / p.tile_stride;
+    p.ntiles = 0;                                    // set by the launcher of the chosen tile shape
     p.cand_s = cand_s; p.cand_t = cand_t; p.cnt = cnt; p.lost = lost; p.cap = cap;
-    if (t.dt == VDB_F32) return launch_gemm32s_mode<VDB_BF16, 0>(p, nq, n_cu, st);
+    if (t.dt == VDB_F32) return split ? launch_gemm32s_mode<VDB_BF16, 0>(p, nq, n_cu, st) : launch_gemm32s_mode<VDB_BF16, 3>(p, nq, n_cu, st);
     if (t.dt == VDB_BF16) return split ? launch_gemm32s_mode<VDB_BF16, 1>(p, nq, n_cu, st) : launch_gemm32s_mode<VDB_BF16, 2>(p, nq, n_cu, st);
     return split ? launch_gemm32s_mode<VDB_F16, 1>(p, nq, n_cu, st) : launch_gemm32s_mode<VDB_F16, 2>(p, nq, n_cu, st);
 }
@@ -1089,7 +1173,7 @@ hipError_t launch_gemm32s(const TableView& t, const unsigned short* qhi, const u
 static int g_gemm16_variant = 0;
 void set_gemm16_variant(int v) { g_gemm16_variant = v; }
 
-hipError_t launch_gemm16_thresh(const TableView& t, const unsigned short* qhi, const unsigned short* qlo,
+hipError_t launch_gemm16_thresh(const TableView& t, const unsigned short* qhi, const unsigned short* qlo, int qstride,
                                 int split, int nq, int dpad, const float* thr,
                                 long long tile0, long long tile_stride, long long ntiles,
                                 float* cand_s, long long* cand_t, int* cnt, int* lost, int cap, int dense,
@@ -1097,7 +1181,7 @@ hipError_t launch_gemm16_thresh(const TableView& t, const unsigned short* qhi, c
     if (ntiles <= 0) return hipSuccess;
     Gemm16Params p;
     p.X = (const unsigned short*)t.rows; p.n2 = t.n2; p.Qhi = qhi; p.Qlo = qlo; p.thr = thr; p.n = t.n; p.nq = nq;
-    p.dpad = dpad; p.ldx = t.m * 8; p.l2 = t.metric == VDB_METRIC_L2 ? 1 : 0;
+    p.dpad = dpad; p.ldq = qstride; p.ldx = t.m * 8; p.l2 = t.metric == VDB_METRIC_L2 ? 1 : 0;
     p.tile0 = tile0; p.tile_stride = tile_stride; p.ntiles = ntiles;
     p.cand_s = cand_s; p.cand_t = cand_t; p.cnt = cnt; p.lost = lost; p.cap = cap;
     const int qtiles = (nq + HB_N - 1) / HB_N;
@@ -1114,7 +1198,7 @@ hipError_t launch_gemm16_thresh(const TableView& t, const unsigned short* qhi, c
     // wide-tile kernel; otherwise the 128 x 128 tile kernel (unsplit) or the streaming kernel (split).
     const bool full = tile0 == 0 && tile_stride == 1 && ntiles == (t.n + HB_M - 1) / HB_M;
     if (!dense && full && ((g_gemm16_variant == 0 && split && nq <= 64) || g_gemm16_variant == 13))
-        return launch_gemm32s(t, qhi, qlo, dpad, split, nq, dpad, thr, 1, cand_s, cand_t, cnt, lost, cap, n_cu, st);
+        return launch_gemm32s(t, qhi, qlo, qstride, split, nq, dpad, thr, 1, cand_s, cand_t, cnt, lost, cap, n_cu, st);
     if (!dense && full && nq > HB_N && (g_gemm16_variant == 0 || g_gemm16_variant == 12)) {
         Gemm16Params w = p;
         w.ntiles = (t.n + WB_M - 1) / WB_M;

@@ -605,7 +605,6 @@ __device__ __forceinline__ int rank_of(const float* V, int n, int i, float vi) {
 // head is a lower bound of the K-th best key overall; everything below it is dropped with one
 // compare per candidate, and the exact K best are radix-selected among the few survivors.  The
 // K rows are then re-scored canonically, sorted by (score, id) and the answer is certified.
-template <bool FLAT>
 __global__ void __launch_bounds__(1024)
 finalize_kernel(FinParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -625,12 +624,8 @@ finalize_kernel(FinParams p) {
     int*       VI   = (int*)(VS + FIN_CAP);             // FIN_CAP survivor positions
 
     const int qi = blockIdx.x;
-    long long M = (long long)p.G * K;
-    size_t qoff = (size_t)qi * M;
-    if (FLAT) {
-        M = p.flat_cnt[qi] < p.flat_cap ? p.flat_cnt[qi] : p.flat_cap;
-        qoff = (size_t)qi * p.flat_cap;
-    }
+    const long long M = (long long)p.G * K;
+    const size_t qoff = (size_t)qi * M;
     const float*     gs = p.cand_s + qoff;
     const long long* gt = p.cand_t + qoff;
 
@@ -649,7 +644,7 @@ finalize_kernel(FinParams p) {
 
     // (A) lower bound from the list heads; (B) walk only the lists whose head survives it
     uint32_t lb = 0;
-    const bool heads_in_regs = !FLAT && p.G <= 8 * nth;
+    const bool heads_in_regs = p.G <= 8 * nth;
     if (heads_in_regs) {
         const float* gh = p.cand_h + (size_t)qi * p.G;
         // thread t owns the lpt consecutive lists t*lpt ... (the waves of one scan block)
@@ -692,7 +687,7 @@ finalize_kernel(FinParams p) {
                 }
             }
         }
-    } else if (!FLAT) {
+    } else {
         if (p.G > K) {
             int nd;
             const bool all = select_kth([&](long long b, int) { return gs[b * K]; }, (long long)p.G, K, hist, ctl, lb, nd, 2);
@@ -722,7 +717,7 @@ finalize_kernel(FinParams p) {
     __syncthreads();
     STAMP(2);
     const int S = ctl[5];
-    if (!FLAT && S <= FIN_RANK_MAX) {
+    if (S <= FIN_RANK_MAX) {
         // (C) few survivors: rank them directly; the K best land in SS/ST already ordered
         take_all = S <= K;
         for (int j = tid; j < S; j += nth) {
@@ -734,7 +729,7 @@ finalize_kernel(FinParams p) {
         __syncthreads();
         thr = (uint32_t)ctl[7];
         if (tid == 0) ctl[4] = S;
-    } else if (!FLAT && S <= FIN_CAP) {
+    } else if (S <= FIN_CAP) {
         // (C) exact K best among the survivors
         take_all = select_kth([&](long long j, int) { return VS[j]; }, (long long)S, K, hist, ctl, thr, need);
         for (int j = tid; j < S; j += nth) {
@@ -760,7 +755,7 @@ finalize_kernel(FinParams p) {
     }
     __syncthreads();
     STAMP(3);
-    if (!FLAT && p.floor_out) {
+    if (p.floor_out) {
         // threshold-only use: the K-th best key of these lists bounds the K-th best key of any
         // superset of their rows from below
         if (tid == 0) p.floor_out[qi] = take_all ? neg_inf() : fkey_inv(thr);
@@ -816,14 +811,11 @@ finalize_kernel(FinParams p) {
         if (lane == 0) {
             p.out_counts[qi] = cnt;
             // lists mode with fewer candidates than K: every stored row is among them
-            bool cert = !FLAT && nvalid < K;
-            const bool usable = !FLAT || (p.flat_lost[qi] == 0 && (p.flat_bad == nullptr || p.flat_bad[qi] == 0) &&
-                                         (long long)cnt == (p.t.n < p.k ? p.t.n : (long long)p.k));
-            if (!cert && cnt > 0 && usable) {
+            bool cert = nvalid < K;
+            if (!cert && cnt > 0) {
                 // theta: no row outside the candidate set has a larger fast key
                 double theta = (double)fkey_inv(prefix);
                 if (take_all) { float mn = SS[0]; for (int i = 1; i < nvalid; ++i) mn = fminf(mn, SS[i]); theta = (double)mn; }
-                if (FLAT) { const double tau = (double)p.flat_tau[qi]; if (take_all || tau > theta) theta = tau; }
                 const double bx = sqrt((double)(*p.t.max_n2)) * (1.0 + 1e-6);
                 const double bq = (double)p.qinfo[qi].bq;
                 const double u = 5.9604644775390625e-08;   // 2^-24
@@ -847,6 +839,116 @@ finalize_kernel(FinParams p) {
     }
 }
 
+constexpr int BAND_CAP = 2048;    // most rows one query re-scores on the batched path
+
+// Batched path, one block per query.  The flat candidate array holds every row whose fast key
+// exceeds tau, unsorted.  Let f_k be the k-th best fast key and eps a bound of
+// |fast key - canonical key| (canonical keys shifted by the query's squared norm for L2).  The k rows
+// with the best fast keys have canonical keys >= f_k - eps, so the k-th best canonical key is at
+// least that, and a row whose canonical key reaches it has a fast key >= f_k - 2 eps.  Every
+// candidate in that band is re-scored canonically and the band is ranked by (score, id): the first
+// k are the answer and nothing is left to certify, however coarse the fast keys are.  A query goes to
+// the exact pass only when the candidates do not cover the band (f_k - 2 eps <= tau, candidates lost
+// to a full array, an unrepresentable query) or the band holds more than BAND_CAP rows.
+__global__ void __launch_bounds__(1024)
+finalize_band_kernel(FinParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nth = blockDim.x;
+    const int W = nth >> 6;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    int*       hist = (int*)smem;                       // 256 bins
+    int*       ctl  = hist + 256;                       // 16 control words
+    long long* ST   = (long long*)(smem + 1088);        // BAND_CAP rows of the band
+    long long* RT   = ST + BAND_CAP;                    // their ids
+    float*     RS   = (float*)(RT + BAND_CAP);          // their canonical keys
+
+    const int qi = blockIdx.x;
+    const long long M = p.flat_cnt[qi] < p.flat_cap ? p.flat_cnt[qi] : p.flat_cap;
+    const float*     gs = p.cand_s + (size_t)qi * p.flat_cap;
+    const long long* gt = p.cand_t + (size_t)qi * p.flat_cap;
+    const bool l2 = p.t.metric == VDB_METRIC_L2;
+    if (tid < 16) ctl[tid] = 0;
+    __syncthreads();
+
+    // every decision below is block-uniform
+    bool ok = p.flat_lost[qi] == 0 && (p.flat_bad == nullptr || p.flat_bad[qi] == 0) && M > p.k;
+    uint32_t thr = 0;
+    int need = 0;
+    if (ok) {
+        const bool all = select_kth([&](long long i, int) { return gs[i]; }, M, p.k, hist, ctl, thr, need);
+        if (all) ok = false;                            // fewer than k usable keys
+    }
+    double band = 0.0;
+    if (ok) {
+        const double fk = (double)fkey_inv(thr);
+        const double bx = sqrt((double)(*p.t.max_n2)) * (1.0 + 1e-6);
+        const double bq = (double)p.qinfo[qi].bq;
+        const double u = 5.9604644775390625e-08;        // 2^-24
+        const double dd = (double)p.t.d * p.dd_mult + 16.0;
+        const double xq = p.extra_rel * bx * bq + p.extra_abs * bx;
+        double eps;
+        if (!l2) eps = 1.05 * dd * u * bx * bq + xq;
+        else eps = 1.05 * u * (2.0 * dd * bx * bq + 4.0 * (bx * bx + 2.0 * bx * bq)) + 2.0 * xq + 4.0 * u * (bx + bq) * (bx + bq);
+        eps = (eps + 4.0 * u * fabs(fk) + 1e-37) * 1.001;
+        eps += 8.0 * u * eps;                           // keys in the band are up to 2 eps away from f_k
+        band = fk - 2.0 * eps;
+        if (!(band > (double)p.flat_tau[qi])) ok = false;     // also catches a non-finite bound
+    }
+    if (ok) {
+        for (long long i0 = 0; i0 < M; i0 += nth) {
+            const long long i = i0 + tid;
+            const bool in = i < M && (double)gs[i] >= band;
+            const unsigned long long m = __ballot(in);
+            if (m) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&ctl[5], __popcll(m));
+                base = __shfl(base, 0);
+                const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+                if (in && pos < BAND_CAP) ST[pos] = gt[i];
+            }
+        }
+        __syncthreads();
+        if (ctl[5] > BAND_CAP) ok = false;
+    }
+    if (!ok) {
+        if (tid == 0) {
+            const int pos = atomicAdd(&p.need_exact[0], 1);
+            p.need_exact[1 + pos] = qi;
+            atomicAdd((unsigned long long*)&p.counters[0], 1ull);
+        }
+        return;
+    }
+    const int S = ctl[5];                               // >= k: the k best fast keys are in the band
+    const float* q = p.q + (size_t)qi * p.dpad;
+    const size_t rowbytes = (size_t)p.t.m * 16;
+    for (int i = wave; i < S; i += W) {
+        const long long r = ST[i];
+        const double sc = canon_score(p.t.rows + (size_t)r * rowbytes, q, p.t.d, p.t.dt, l2, lane);
+        const float f = (float)sc;
+        if (lane == 0) { RS[i] = l2 ? -f : f; RT[i] = p.t.ids[r]; }
+    }
+    __syncthreads();
+    for (int j = tid; j < S; j += nth) {
+        const float ms = RS[j];
+        const long long mt = RT[j];
+        int rank = 0;
+        for (int i = 0; i < S; ++i) {
+            const float si = RS[i];
+            const long long ti = RT[i];
+            rank += (better(si, ti, ms, mt) || (si == ms && ti == mt && i < j)) ? 1 : 0;
+        }
+        if (rank < p.k) {
+            p.out_ids[(size_t)qi * p.k + rank] = mt;
+            p.out_scores[(size_t)qi * p.k + rank] = l2 ? -ms : ms;
+        }
+    }
+    if (tid == 0) {
+        p.out_counts[qi] = p.k;
+        atomicAdd((unsigned long long*)&p.counters[0], 1ull);
+    }
+}
+
 hipError_t launch_finalize(const TableView& t, const float* qprep, const QInfo* qinfo, int64_t nq,
                            int dpad, const SelGeom& g, int G, int k,
                            const float* cand_s, const long long* cand_t, const float* cand_h,
@@ -862,9 +964,9 @@ hipError_t launch_finalize(const TableView& t, const float* qprep, const QInfo* 
     p.dd_mult = 1.0; p.extra_rel = 0.0; p.extra_abs = 0.0; p.floor_out = nullptr;
     int kr = 1; while (kr < g.K) kr <<= 1;
     const size_t lds = 1088 + (size_t)g.K * 12 + (size_t)kr * 12 + (size_t)FIN_CAP * 8;
-    hipError_t e = allow_lds(finalize_kernel<false>, lds);
+    hipError_t e = allow_lds(finalize_kernel, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((finalize_kernel<false>), dim3((unsigned)nq), dim3(1024), lds, st, p);
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)nq), dim3(1024), lds, st, p);
     return hipGetLastError();
 }
 
@@ -878,9 +980,9 @@ hipError_t launch_lists_floor(const SelGeom& g, int G, int64_t nq, const float* 
     p.floor_out = floor_out;
     int kr = 1; while (kr < g.K) kr <<= 1;
     const size_t lds = 1088 + (size_t)g.K * 12 + (size_t)kr * 12 + (size_t)FIN_CAP * 8;
-    hipError_t e = allow_lds(finalize_kernel<false>, lds);
+    hipError_t e = allow_lds(finalize_kernel, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((finalize_kernel<false>), dim3((unsigned)nq), dim3(1024), lds, st, p);
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)nq), dim3(1024), lds, st, p);
     return hipGetLastError();
 }
 
@@ -898,11 +1000,10 @@ hipError_t launch_finalize_flat(const TableView& t, const float* qprep, const QI
     p.need_exact = need_exact; p.counters = counters;
     p.flat_cnt = cnt; p.flat_cap = cap; p.flat_tau = tau; p.flat_lost = lost; p.flat_bad = bad;
     p.dd_mult = fb.dd_mult; p.extra_rel = fb.extra_rel; p.extra_abs = fb.extra_abs; p.floor_out = nullptr;
-    int kr = 1; while (kr < g.K) kr <<= 1;
-    const size_t lds = 1088 + (size_t)g.K * 12 + (size_t)kr * 12 + (size_t)FIN_CAP * 8;
-    hipError_t e = allow_lds(finalize_kernel<true>, lds);
+    const size_t lds = 1088 + (size_t)BAND_CAP * 20;
+    hipError_t e = allow_lds(finalize_band_kernel, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((finalize_kernel<true>), dim3((unsigned)nq), dim3(1024), lds, st, p);
+    hipLaunchKernelGGL(finalize_band_kernel, dim3((unsigned)nq), dim3(1024), lds, st, p);
     return hipGetLastError();
 }
 

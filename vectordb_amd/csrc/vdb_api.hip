@@ -80,7 +80,7 @@ struct Global {
     double cache_capacity_gb = 0.0;
     double insert_buffer_gb = 1.0;
     size_t table_bytes = 0;
-    int tune_nt = 1, tune_waves = 8, tune_bpc = 4, tune_contig = 1, tune_gemm = 1, tune_split_f16 = 0, tune_sample = 1, tune_gemm32s = 1;
+    int tune_nt = 1, tune_waves = 8, tune_bpc = 4, tune_contig = 1, tune_gemm = 1, tune_split_f16 = 0, tune_split_bf16 = 0, tune_sample = 1, tune_gemm32s = 2;
     // host-insert staging (guarded by insert_mu)
     std::mutex insert_mu;
     DevBuf stage_rows, stage_ids;
@@ -327,16 +327,21 @@ static int search_gemm_path(const TableView& tv, const SelGeom& g, int dpad, int
     size_t slots = (size_t)nqc * GEMM_CAP;
     if ((size_t)nqc * Gx * K > slots) slots = (size_t)nqc * Gx * K;
     const bool half = tv.dt != VDB_F32;
-    // bf16 carries 8 significant bits: always use both parts; fp16 carries 11: the hi part alone
-    // leaves a relative query error of 2^-11, which the certificate accounts for
-    const int split = tv.dt == VDB_BF16 ? 1 : (G.tune_split_f16 ? 1 : 0);
-    // fp32 tables: the full pass runs on the 16-bit matrix unit with rows and queries presented as
-    // bf16 hi + lo and three products per term (relative error 3 * 2^-16 per term, in the bound below)
+    // 16-bit tables: the query rounded to the table's type leaves a relative error of 2^-9 (bf16) or
+    // 2^-11 (fp16) of ||x|| ||q|| in the fast keys; the finalize step re-scores every candidate within
+    // twice the error bound of the k-th best fast key, so a coarse pass only widens that band.  With
+    // the split options the query goes in as hi + lo parts instead (two products, narrow band).
+    const int split = tv.dt == VDB_BF16 ? (G.tune_split_bf16 ? 1 : 0) : (G.tune_split_f16 ? 1 : 0);
+    // fp32 tables run on the 16-bit matrix unit as well: rows and queries rounded to bf16 (one
+    // product per term, relative error 2^-8), or presented as bf16 hi + lo with three products per
+    // term (relative error 3 * 2^-16) when gemm32_split is 1
     const bool s32 = !half && G.tune_gemm32s != 0;
-    const int qstride = (dpad + 7) / 8 * 8;
+    const int s32split = G.tune_gemm32s == 1 ? 1 : 0;
+    const int qstride = (dpad + 31) / 32 * 32;       // 16-bit query rows: zero padded to whole k-steps of the kernels
     FlatBound fb;
-    fb.dd_mult = s32 ? 3.0 : ((half && split) ? 2.0 : 1.0);
-    fb.extra_rel = s32 ? 5.0e-5 : (!half ? 0.0 : (tv.dt == VDB_BF16 ? 1.6e-5 : (split ? 2.5e-7 : 4.9e-4)));
+    fb.dd_mult = s32 ? (s32split ? 3.0 : 1.0) : ((half && split) ? 2.0 : 1.0);
+    fb.extra_rel = s32 ? (s32split ? 5.0e-5 : 3.92e-3)
+                       : (!half ? 0.0 : (tv.dt == VDB_BF16 ? (split ? 1.6e-5 : 1.96e-3) : (split ? 2.5e-7 : 4.9e-4)));
     fb.extra_abs = tv.dt == VDB_F16 ? 3.0e-8 * std::sqrt((double)tv.d) : 0.0;      // fp16 subnormal steps
     int rc;
     if ((rc = ensure(ws.qprep, (size_t)nqc * dpad * sizeof(float), ws.last_stream))) return rc;
@@ -361,12 +366,12 @@ static int search_gemm_path(const TableView& tv, const SelGeom& g, int dpad, int
         unsigned short* qhi = (unsigned short*)ws.q16.p;
         unsigned short* qlo = (half || s32) ? qhi + (size_t)nqc * qstride : nullptr;
         auto gemm = [&](const TableView& v, const float* thr, long long stride, long long tiles, int dense) -> hipError_t {
-            if (half) return launch_gemm16_thresh(v, qhi, qlo, split, nqi, dpad, thr, 0, stride, tiles, cs, ct, cnt, lost, GEMM_CAP, dense, G.n_cu, st);
+            if (half) return launch_gemm16_thresh(v, qhi, qlo, qstride, split, nqi, dpad, thr, 0, stride, tiles, cs, ct, cnt, lost, GEMM_CAP, dense, G.n_cu, st);
             return launch_gemm_thresh(v, qprep, nqi, dpad, thr, 0, stride, tiles, cs, ct, cnt, lost, GEMM_CAP, dense, G.n_cu, st);
         };
         VDB_HIP(launch_prep_query(q_dev + (size_t)q0 * tv.d, nqi, tv.d, dpad, tv.metric, qprep, qinfo, ne, st));
         VDB_HIP(hipMemsetAsync(bad, 0, (size_t)nqc * 4, st));
-        if (half) VDB_HIP(launch_split_query16(tv.dt, qprep, nqi, dpad, dpad, qhi, qlo, bad, st));
+        if (half) VDB_HIP(launch_split_query16(tv.dt, qprep, nqi, dpad, qstride, qhi, qlo, bad, st));
         if (s32) VDB_HIP(launch_split_query16(VDB_BF16, qprep, nqi, dpad, qstride, qhi, qlo, bad, st));
         // pass 0: every score of the first n0 (<= GEMM_CAP) rows is kept, row r in slot r (no
         // counter traffic: a million atomics on nq addresses cost more than the whole pass);
@@ -382,7 +387,7 @@ static int search_gemm_path(const TableView& tv, const SelGeom& g, int dpad, int
             // strided sample of `tiles` row tiles under the current threshold -> next threshold
             const long long stride = ntiles / tiles;
             VDB_HIP(hipMemsetAsync(cnt, 0, (size_t)nqc * 8, st));
-            if (s32) VDB_HIP(launch_gemm32s(tv, qhi, qlo, qstride, 1, nqi, dpad, tau, stride, cs, ct, cnt, lost, GEMM_CAP, G.n_cu, st));
+            if (s32) VDB_HIP(launch_gemm32s(tv, qhi, qlo, qstride, s32split, nqi, dpad, tau, stride, cs, ct, cnt, lost, GEMM_CAP, G.n_cu, st));
             else VDB_HIP(gemm(tv, tau, stride, ntiles / stride, 0));
             VDB_HIP(launch_kth_threshold(cs, GEMM_CAP, cnt, 0, GEMM_CAP, K, tau, spare, nqi, st));
             std::swap(tau, spare);
@@ -391,7 +396,7 @@ static int search_gemm_path(const TableView& tv, const SelGeom& g, int dpad, int
         VDB_HIP(hipMemsetAsync(cnt, 0, (size_t)nqc * 8, st));
         ProfScope prof;
         if ((rc = prof.begin(st))) return rc;
-        if (s32) VDB_HIP(launch_gemm32s(tv, qhi, qlo, qstride, 1, nqi, dpad, tau, 1, cs, ct, cnt, lost, GEMM_CAP, G.n_cu, st));
+        if (s32) VDB_HIP(launch_gemm32s(tv, qhi, qlo, qstride, s32split, nqi, dpad, tau, 1, cs, ct, cnt, lost, GEMM_CAP, G.n_cu, st));
         else VDB_HIP(gemm(tv, tau, 1, ntiles, 0));
         if ((rc = prof.end(st))) return rc;
         VDB_HIP(launch_finalize_flat(tv, qprep, qinfo, nqi, dpad, g, k, cs, ct, cnt, GEMM_CAP, tau, lost, bad, fb,
@@ -426,7 +431,7 @@ static int search_core(Table& t, int64_t nq, const float* q_dev, int k, long lon
         // few scans undercut.  Both estimates are fits of measured times (seconds; row bytes B).
         const double B = (double)tv.n * tv.m * 16.0;
         const double pass_rate = tv.dt == VDB_F32 ? (nq <= 32 ? 5.0e12 : nq <= 64 ? 4.2e12 : 3.8e12)
-                                                  : (tv.dt == VDB_BF16 || G.tune_split_f16 ? (nq <= 64 ? 3.2e12 : 2.3e12) : 4.0e12);
+                                                  : ((tv.dt == VDB_BF16 ? G.tune_split_bf16 : G.tune_split_f16) ? (nq <= 64 ? 3.2e12 : 2.3e12) : 4.0e12);
         const double est_scan = 60e-6 + (double)nq * (20e-6 + B / 6.5e12);
         const double est_gemm = 270e-6 + (double)((nq + 127) / 128) * B / pass_rate;
         if (est_scan < est_gemm) gemm = false;
@@ -596,7 +601,9 @@ int vdb_set_option(const char* key, double value) {
     else if (k == "scan_sample") G.tune_sample = value != 0;
     else if (k == "gemm_path") G.tune_gemm = value != 0;
     else if (k == "gemm_split_f16") G.tune_split_f16 = value != 0;
-    else if (k == "gemm32_split") G.tune_gemm32s = value != 0;
+    else if (k == "gemm32_split") G.tune_gemm32s = value < 0 ? 0 : value > 2 ? 2 : (int)value;
+    else if (k == "gemm_split_bf16") G.tune_split_bf16 = value != 0;
+    else if (k == "gemm32s_threads") set_gemm32s_threads((int)value);
     else if (k == "gemm16_variant") set_gemm16_variant((int)value);
     else return fail(VDB_EINVAL, "unknown option: " + k);
     set_scan_tune(G.tune_nt, G.tune_waves, G.tune_bpc, G.tune_contig);
