@@ -251,43 +251,43 @@ def main() -> None:
         except (OSError, ValueError):
             pass
         if batched > 0:
-            # batched path: the dominant kernel is the fp32 MFMA GEMM over all rows (one launch per
-            # 1024-query chunk); algorithmic flops = 2 * rows * dim * queries per launch
+            # batched path: the dominant kernel is the MFMA GEMM of the last threshold pass over all rows
+            # (one launch per 1024-query chunk); algorithmic flops = 2 * rows * dim * queries per launch
             nq_launch = min(args.nq, 1024)
             flops = 2.0 * n_local * args.dim * nq_launch
             tf = flops / avg_scan_s / 1e12 if avg_scan_s > 0 else 0.0
-            split32 = args.dtype == "f32" and "gemm32_split=0" not in args.opt
-            if split32:
-                # fp32 rows on the 16-bit matrix unit: rows and queries as bf16 hi + lo, three products per
-                # term, so the ceiling for algorithmic flops is the dense bf16 peak / 3
-                peak = 2500.0 / 3.0
-                line["dtype"] = "f32 rows; fast pass bf16 hi+lo x3 on MFMA, f32 accumulate; fp64 re-score"
-                line["roofline"] = {
-                    "bound": "mfma", "kernel": "gemm32s_kernel", "achieved": tf, "peak": peak,
-                    "unit": "TFLOP/s", "frac": tf / peak, "traffic": None,
-                    "flops_per_launch": flops, "mfma_flops_per_launch": 3.0 * flops,
-                    "avg_launch_ms": avg_scan_s * 1e3, "launches_timed": scan_launches,
-                }
-                if args.nq < 128:
-                    # less than one 128-query tile: the pass is bound by reading the rows once
-                    line["roofline"].update({"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                             "frac": achieved / HBM_PEAK_GBS, "bytes_per_launch": bytes_per_launch,
-                                             "algorithmic_tflops": tf})
-            elif args.dtype == "f32":
+            opts = dict(o.split("=", 1) for o in args.opt)
+            if args.dtype == "f32" and opts.get("gemm32_split") == "0":
                 line["roofline"] = {
                     "bound": "mfma", "kernel": "gemm_thresh_kernel", "achieved": tf, "peak": MFMA_F32_PEAK_TF,
                     "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF, "traffic": None,
                     "flops_per_launch": flops, "avg_launch_ms": avg_scan_s * 1e3, "launches_timed": scan_launches,
                 }
             else:
-                # 16-bit rows: 16x the MFMA rate, so up to a few hundred queries per batch the GEMM
-                # is bound by streaming the rows once per 128-query tile (shared through L2)
+                # every table type runs its batched passes on the 16-bit matrix unit: fp32 rows rounded
+                # to bf16 on the way to LDS (one product per term; gemm32_split=1: bf16 hi + lo, three
+                # products), 16-bit rows as stored (query rounded once, or hi + lo: two products).  The
+                # ceiling for algorithmic flops is the dense 16-bit peak / products per term.
+                if args.dtype == "f32":
+                    products = 3 if opts.get("gemm32_split") == "1" else 1
+                    line["dtype"] = ("f32 rows; fast pass bf16 hi+lo x3 on MFMA" if products == 3 else
+                                     "f32 rows; fast pass rounded to bf16 on MFMA") + ", f32 accumulate; fp64 re-score"
+                else:
+                    products = 2 if opts.get("gemm_split_" + args.dtype) == "1" else 1
+                    line["dtype"] = args.dtype + " rows on MFMA, f32 accumulate; fp64 re-score"
+                peak = 2500.0 / products
                 line["roofline"] = {
-                    "bound": "hbm", "kernel": "gemm16_wide_kernel" if args.nq > 128 else "gemm16_thresh_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                    "bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_scan_s * 1e3,
-                    "launches_timed": scan_launches, "mfma_tflops": tf, "mfma_frac_of_2500": tf / 2500.0,
+                    "bound": "mfma", "kernel": "gemm32s_kernel", "achieved": tf, "peak": peak,
+                    "unit": "TFLOP/s", "frac": tf / peak, "traffic": None,
+                    "flops_per_launch": flops, "mfma_flops_per_launch": products * flops,
+                    "avg_launch_ms": avg_scan_s * 1e3, "launches_timed": scan_launches,
+                    "row_bytes_per_launch": bytes_per_launch, "row_read_gbs_if_read_once": achieved,
                 }
+                if args.nq < 128:
+                    # less than one 128-query tile: the pass is bound by reading the rows once
+                    line["roofline"].update({"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                             "frac": achieved / HBM_PEAK_GBS, "bytes_per_launch": bytes_per_launch,
+                                             "algorithmic_tflops": tf})
         if world == 1 and args.cpu_seconds > 0 and args.nq == 1:
             line["cpu_baseline"] = cpu_baseline(args.rows, args.dim, args.k, args.metric, args.cpu_seconds)
         print(json.dumps(line), flush=True)

@@ -72,13 +72,15 @@ int vdb_shutdown(void);
  * different streams run one after the other, chained by events, while the short kernels around
  * them overlap; 0 = scans of different streams may overlap); "scan_sample" (1 = for long candidate
  * lists over short rows, a scan of 1/256 of the rows first supplies a threshold floor to the full scan).
- * Batched path: "gemm_path" (0 sends every batch through the scan path), "gemm_split_f16"
- * (1 splits fp32 queries into hi + lo halves for fp16 tables as is always done for bf16),
- * "gemm32_split" (1 = fp32 tables, 64 queries or more: full pass on the 16-bit MFMA with bf16 hi + lo
- * operands, three products per term; 0 = fp32 MFMA),
- * "gemm16_variant" (0 = chosen by shape, 1 = register-streaming kernel, 11 = 128x128 LDS-tiled
- * kernel, 12 = 256x256 wide-tile kernel for full passes over more than 128 queries, 13 = the 256-row
- * kernel of the fp32 tables). */
+ * Batched path (all its passes run on the 16-bit matrix unit; the finalize step re-scores every
+ * candidate within twice the error bound of the k-th best fast key, so a coarser pass costs
+ * re-scoring, never exactness): "gemm_path" (0 sends every batch through the scan path),
+ * "gemm32_split" (fp32 tables: 2 = rows and queries rounded to bf16, one product per term (default);
+ * 1 = bf16 hi + lo parts, three products per term; 0 = fp32 MFMA),
+ * "gemm_split_bf16" / "gemm_split_f16" (1 = the fp32 query goes in as hi + lo parts of the table's
+ * type, two products per term; default 0: rounded once),
+ * "gemm32s_threads" (workgroup shape of the 256-query tile: 512 = 8 waves over 256 rows (default),
+ * 256 = 4 waves over 128 rows, two workgroups per CU). */
 int vdb_set_option(const char* key, double value);
 const char* vdb_last_error(void);
 

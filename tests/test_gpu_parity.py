@@ -397,8 +397,9 @@ def test_batched_path_matches_scan_path(engine, table_name):
 @pytest.mark.parametrize("metric", ["ip", "cosine", "l2"])
 @pytest.mark.parametrize("d,nq", [(96, 33), (200, 150), (768, 24)])
 def test_batched_gemm_path_16bit_parity(engine, table_name, metric, dtype, d, nq):
-    """bf16 / fp16 tables: the batch runs on the 16-bit MFMA with the query split into hi + lo
-    parts (bf16) or rounded once (fp16); results must still be the oracle's bit for bit."""
+    """bf16 / fp16 tables: the batch runs on the 16-bit MFMA with the query rounded once to the
+    table's type (default) or split into hi + lo parts (`gemm_split_bf16` / `gemm_split_f16`);
+    results must be the oracle's bit for bit either way."""
     n = 70_000
     rows = cases.make_rows("synth", 300 + d, n, d)
     ids = cases.make_ids("hash", 300 + d, n)
@@ -409,37 +410,61 @@ def test_batched_gemm_path_16bit_parity(engine, table_name, metric, dtype, d, nq
     _check(engine, table_name, stored, ids, q, 10, m)
     after = engine.stats()
     assert after[2] - before[2] == nq, "the batch did not take the GEMM path"
-    if dtype == "f16":
-        engine.set_option("gemm_split_f16", 1)
-        try:
-            _check(engine, table_name, stored, ids, q, 10, m)
-        finally:
-            engine.set_option("gemm_split_f16", 0)
+    opt = "gemm_split_f16" if dtype == "f16" else "gemm_split_bf16"
+    engine.set_option(opt, 1)
+    try:
+        _check(engine, table_name, stored, ids, q, 10, m)
+    finally:
+        engine.set_option(opt, 0)
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "f16"])
-@pytest.mark.parametrize("variant", [1, 11, 12, 13])
-def test_each_16bit_gemm_kernel_parity(engine, table_name, variant, dtype):
-    """The library picks one of four 16-bit batched kernels by shape (128 x 128 LDS-staged tile
-    kernel, row fragments streamed straight to registers, 256 x 256 wide-tile kernel, the 256-row
-    kernel shared with the fp32 tables); forced
-    through the `gemm16_variant` option each must give the same exact results for split (bf16)
-    and unsplit (fp16) queries.  150 queries: more than one 128-query tile, a ragged last tile."""
-    n, d, nq = 70_000, 200, 150
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("threads", [256, 512])
+def test_256_query_tile_both_workgroup_shapes(engine, table_name, threads, dtype):
+    """More than 128 queries take 256-query tiles, as one workgroup of 8 waves over 256 rows or as
+    workgroups of 4 waves over 128 rows (`gemm32s_threads`); same exact results.  150 queries: one
+    ragged tile; 70 001 rows: a ragged last row tile of either height."""
+    n, d, nq = 70_001, 200, 150
     rows = cases.make_rows("synth", 41, n, d)
     ids = cases.make_ids("hash", 41, n)
     q = cases.make_queries("synth", 41, nq, d, rows)
     stored = _load(engine, table_name, rows, ids, O.L2, cases.DTYPES[dtype])
-    engine.set_option("gemm16_variant", variant)
+    engine.set_option("gemm32s_threads", threads)
     try:
+        before = engine.stats()[2]
         _check(engine, table_name, stored, ids, q, 10, O.L2)
+        assert engine.stats()[2] - before == nq
     finally:
-        engine.set_option("gemm16_variant", 0)
+        engine.set_option("gemm32s_threads", 512)
+
+
+def test_band_wider_than_its_buffer_goes_to_the_exact_pass(engine, table_name):
+    """3000 stored copies of one vector: for a query equal to it the re-score band of the batched
+    path holds more rows than its buffer (2048), so those queries are answered by the exact pass --
+    ten of the copies, ordered by id -- while the other queries of the batch stay on the fast path."""
+    n, d, nq = 70_000, 64, 40
+    rows = cases.make_rows("synth", 45, n, d)
+    rows[10_000:13_000] = rows[10_000]
+    ids = cases.make_ids("hash", 45, n)
+    q = cases.make_queries("synth", 45, nq, d, rows)
+    q[3] = rows[10_000]
+    q[17] = rows[10_000]
+    for metric in (O.COSINE, O.L2):
+        name = table_name + "_%d" % metric
+        stored = _load(engine, name, rows, ids, metric, O.F32)
+        try:
+            before = engine.stats()
+            _check(engine, name, stored, ids, q, 10, metric)
+            after = engine.stats()
+            assert after[2] - before[2] == nq
+            assert 2 <= after[1] - before[1] < nq
+        finally:
+            engine.drop_table(name)
 
 
 def test_wide_batch_default_kernel_choice(engine, table_name):
-    """More than two query tiles (nq > 256) on an fp16 table with the default kernel choice and a
-    row count that is not a multiple of the 256-row tile; results stay exact."""
+    """More than one 256-query tile (nq > 256) on an fp16 table and a row count that is not a
+    multiple of the 256-row tile; results stay exact."""
     n, d, nq = 66_001, 64, 300
     rows = cases.make_rows("synth", 43, n, d)
     ids = cases.make_ids("index", 43, n)
@@ -507,13 +532,14 @@ def test_sampled_floor_scan_parity(engine, table_name, metric, dtype, kind):
         assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("split", [1, 0])
+@pytest.mark.parametrize("split", [2, 1, 0])
 @pytest.mark.parametrize("metric", ["ip", "cosine", "l2"])
-@pytest.mark.parametrize("d,nq", [(100, 130), (768, 70), (36, 64)])
-def test_batched_fp32_table_both_fast_pass_modes(engine, table_name, metric, d, nq, split):
-    """fp32 tables, 64 queries or more: the full pass runs on the 16-bit matrix unit with bf16 hi + lo
-    operands (`gemm32_split` 1, default) or on the fp32 MFMA (0).  Same exact results either way;
-    dims that are not multiples of 8 exercise the zero padding of the split queries."""
+@pytest.mark.parametrize("d,nq", [(100, 130), (768, 70), (36, 64), (20, 31)])
+def test_batched_fp32_table_all_fast_pass_modes(engine, table_name, metric, d, nq, split):
+    """fp32 tables: the passes run on the 16-bit matrix unit with rows and queries rounded to bf16
+    (`gemm32_split` 2, default) or presented as bf16 hi + lo with three products (1), or on the fp32
+    MFMA (0).  Same exact results in every mode; dims that are not multiples of 8 exercise the zero
+    padding of the 16-bit queries, dims of one or two k-steps the stages past the last tile."""
     n = 70_000
     rows = cases.make_rows("synth", 61, n, d)
     ids = cases.make_ids("hash", 61, n)
@@ -527,25 +553,31 @@ def test_batched_fp32_table_both_fast_pass_modes(engine, table_name, metric, d, 
         after = engine.stats()
         assert after[2] - before[2] == nq           # took the batched path
     finally:
-        engine.set_option("gemm32_split", 1)
+        engine.set_option("gemm32_split", 2)
 
 
-def test_batched_fp32_split_with_large_magnitudes_and_ties(engine, table_name):
-    """Rows with a wide range of magnitudes and quantised duplicates: the bf16 hi + lo fast pass may
-    fail its certificate, never its result."""
+@pytest.mark.parametrize("split", [2, 1])
+def test_batched_fp32_with_large_magnitudes_and_ties(engine, table_name, split):
+    """Rows with a wide range of magnitudes and quantised duplicates: the 16-bit fast passes may send
+    queries to the exact pass (the error bound scales with the largest row norm), never change a
+    result."""
     n, d, nq = 70_000, 64, 80
     rows = cases.make_rows("ties", 63, n, d)
     rows[::7] *= 1000.0
     rows[1::11] *= 1e-4
     ids = cases.make_ids("negdesc", 63, n)
     q = cases.make_queries("ties", 63, nq, d, rows)
-    for metric in (O.IP, O.L2):
-        name = table_name + "_%d" % metric
-        stored = _load(engine, name, rows, ids, metric, _lib.F32)
-        try:
-            _check(engine, name, stored, ids, q, 10, metric)
-        finally:
-            engine.drop_table(name)
+    engine.set_option("gemm32_split", split)
+    try:
+        for metric in (O.IP, O.L2):
+            name = table_name + "_%d" % metric
+            stored = _load(engine, name, rows, ids, metric, _lib.F32)
+            try:
+                _check(engine, name, stored, ids, q, 10, metric)
+            finally:
+                engine.drop_table(name)
+    finally:
+        engine.set_option("gemm32_split", 2)
 
 
 @pytest.mark.parametrize("metric,dtype,n,d,k,nq", [

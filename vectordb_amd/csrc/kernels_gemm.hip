@@ -282,12 +282,13 @@ hipError_t launch_kth_threshold(const float* cand_s, long long stride, const int
 }  // namespace vdb
 
 // ---------------------------------------------------------------------------------------------
-// 16-bit tables (bf16 / fp16 rows): the same thresholded GEMM on the 16-bit MFMA
-// (v_mfma_f32_32x32x16_{bf16,f16}: exact products, fp32 accumulate, 16x the fp32 MFMA rate).
-// The fp32 query is presented to the MFMA as hi + lo in the rows' 16-bit type (hi = round(q),
-// lo = round(q - hi)); with SPLIT the lo part is accumulated too (relative query error 2^-16 for
-// bf16, 2^-22 for fp16), without it only hi is used (fp16: 2^-11).  That error is part of the
-// bound the certificate uses, so the result stays exact either way.
+// 16-bit MFMA (v_mfma_f32_32x32x16_{bf16,f16}: exact products, fp32 accumulate, 16x the fp32 MFMA
+// rate).  The fp32 query is presented to the MFMA as hi + lo in the rows' 16-bit type
+// (hi = round(q), lo = round(q - hi)); with SPLIT the lo part is accumulated too (relative query
+// error 2^-16 for bf16, 2^-22 for fp16), without it only hi is used (bf16: 2^-9, fp16: 2^-11).
+// That error is part of the bound the finalize step uses, so the result stays exact either way.
+// First the small kernel of the first threshold pass over 16-bit tables (every score of the
+// first rows is kept), then the kernel of all other passes over every table type.
 namespace vdb {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -324,9 +325,10 @@ __device__ __forceinline__ f32x16 mfma16(const u32x4g& a, const u32x4g& b, const
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-template <int DT, bool SPLIT, int D, bool DENSE>
+template <int DT, bool SPLIT>
 __global__ void __launch_bounds__(256, 2)
-gemm16_thresh_kernel(Gemm16Params p) {
+gemm16_dense_kernel(Gemm16Params p) {
+    constexpr int D = 1;                           // k-steps of operands in registers
     __shared__ __attribute__((aligned(16))) unsigned short As[HB_M * HB_LD];
     __shared__ __attribute__((aligned(16))) unsigned short Bh[HB_N * HB_LD];
     __shared__ __attribute__((aligned(16))) unsigned short Bl[SPLIT ? HB_N * HB_LD : 8];
@@ -348,12 +350,6 @@ gemm16_thresh_kernel(Gemm16Params p) {
         if (q > p.nq - 1) q = p.nq - 1;
         qh[i] = p.Qhi + (size_t)q * p.ldq;
         ql[i] = SPLIT ? p.Qlo + (size_t)q * p.ldq : nullptr;
-    }
-    float thr[2];
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int q = qt * HB_N + wn * 64 + ni * 32 + li;
-        thr[ni] = (q < p.nq) ? p.thr[q] : __builtin_huge_valf();
     }
 
     // The (tile, k-step) pairs of this workgroup form one flat sequence of stages.  A ring of D
@@ -454,367 +450,22 @@ gemm16_thresh_kernel(Gemm16Params p) {
                             rn2[r] = n2p[o < nloc ? o : 0];
                         }
                     }
-                    if constexpr (DENSE) {
-#pragma unroll
-                        for (int ni = 0; ni < 2; ++ni) {
-                            const int q = q0 + ni * 32;
-                            const size_t base = (size_t)q * p.cap + (size_t)row0;
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                float key = acc[mi][ni][r];
-                                if (p.l2) key = 2.f * key - rn2[r];
-                                const int lr = lr0 + (r & 3) + 8 * (r >> 2);
-                                if (lr < nloc && q < p.nq) { p.cand_s[base + lr] = key; p.cand_t[base + lr] = row0 + lr; }
-                            }
-                        }
-                        continue;
-                    }
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni) {
+                        const int q = q0 + ni * 32;
+                        const size_t base = (size_t)q * p.cap + (size_t)row0;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             float key = acc[mi][ni][r];
                             if (p.l2) key = 2.f * key - rn2[r];
                             const int lr = lr0 + (r & 3) + 8 * (r >> 2);
-                            if (__builtin_expect(key > thr[ni] && lr < nloc, 0)) {
-                                // rare: keep every address computation inside this block (an opaque
-                                // copy stops the compiler from hoisting 64 row indices out of it)
-                                int lro = lr, q = q0 + ni * 32;
-                                asm volatile("" : "+v"(lro), "+v"(q));
-                                const int pos = atomicAdd(&p.cnt[q], 1);
-                                if (pos < p.cap) { p.cand_s[(size_t)q * p.cap + pos] = key; p.cand_t[(size_t)q * p.cap + pos] = row0 + lro; }
-                                else p.lost[q] = 1;
-                            }
+                            if (lr < nloc && q < p.nq) { p.cand_s[base + lr] = key; p.cand_t[base + lr] = row0 + lr; }
                         }
                     }
                 }
             }
         }
     }
-}
-
-// Streaming variant used for 16-bit tables.  With 16x the MFMA rate the GEMM is bound by reading
-// the rows, so the row operand gets the treatment of the single-query scan: every wave owns 32
-// rows x all 128 queries of the tile and loads its A fragments straight from global memory into
-// registers (16 bytes per lane, a ring of three k-steps in flight, no LDS round trip and no
-// barrier on the row stream); only the query tile, shared by the four waves and served by L2,
-// is staged through LDS.
-template <int DT, bool SPLIT>
-__global__ void __launch_bounds__(256, 2)
-gemm16_stream_kernel(Gemm16Params p) {
-    // the query chunk is double-buffered: chunk ks+1 is written while chunk ks is being read, so one
-    // barrier per k-step suffices and no wave waits for an LDS write it is about to read
-    __shared__ __attribute__((aligned(16))) unsigned short Bh[2][HB_N * HB_LD];
-    __shared__ __attribute__((aligned(16))) unsigned short Bl[2][SPLIT ? HB_N * HB_LD : 8];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 31, lh = lane >> 5;
-    const int qt = blockIdx.y;
-    const int nks = (p.dpad + HB_K - 1) / HB_K;
-    const int d8 = p.dpad >> 3;
-
-    int srow[4], sc8[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { const int f = tid + 256 * i; srow[i] = f >> 3; sc8[i] = f & 7; }
-    const unsigned short* qh[4];
-    const unsigned short* ql[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int q = qt * HB_N + srow[i];
-        if (q > p.nq - 1) q = p.nq - 1;
-        qh[i] = p.Qhi + (size_t)q * p.ldq;
-        ql[i] = SPLIT ? p.Qlo + (size_t)q * p.ldq : nullptr;
-    }
-    float thr[4];
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-        const int q = qt * HB_N + ni * 32 + li;
-        thr[ni] = (q < p.nq) ? p.thr[q] : __builtin_huge_valf();
-    }
-
-    for (long long t = blockIdx.x; t < p.ntiles; t += gridDim.x) {
-        const long long row0 = (p.tile0 + t * p.tile_stride) * HB_M + wave * 32;
-        long long myrow = row0 + li;
-        if (myrow > p.n - 1) myrow = p.n - 1;
-        const unsigned short* xrow = p.X + (size_t)myrow * p.ldx;
-        f32x16 acc[4];
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
-
-        // A fragments of one 64-element k-step: lane (li, lh) holds elements [16*kk + 8*lh, +8) of row li
-        u32x4g abuf[3][4];
-        auto fetch_a = [&](u32x4g (&dst)[4], int ks) {
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int c8 = ks * 8 + kk * 2 + lh;
-                const bool ok = ks < nks && c8 < d8;
-                // plain (cached) loads: four successive loads share each 128-byte line
-                dst[kk] = *(const u32x4g*)(xrow + (ok ? c8 * 8 : 0));        // times a zero query operand
-            }
-        };
-        u32x4g rh[4], rl[4];
-        auto fetch_b = [&](int ks) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int c8 = ks * 8 + sc8[i];
-                const bool ok = c8 < d8;
-                const int c = ok ? c8 * 8 : 0;
-                rh[i] = *(const u32x4g*)(ok ? qh[i] + c : (const unsigned short*)g_zero16);
-                if (SPLIT) rl[i] = *(const u32x4g*)(ok ? ql[i] + c : (const unsigned short*)g_zero16);
-            }
-        };
-        auto store_b = [&](int buf) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                *(u32x4g*)&Bh[buf][srow[i] * HB_LD + sc8[i] * 8] = rh[i];
-                if (SPLIT) *(u32x4g*)&Bl[buf][srow[i] * HB_LD + sc8[i] * 8] = rl[i];
-            }
-        };
-        auto step = [&](const u32x4g (&a)[4], int ks) {
-            const int buf = ks & 1;
-            __syncthreads();          // chunk ks is complete in Bh[buf]; every wave has left chunk ks-1 (buffer buf^1)
-            if (ks + 1 < nks) store_b(buf ^ 1);            // registers hold chunk ks+1 (fetched one step ago)
-            if (ks + 2 < nks) fetch_b(ks + 2);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni) {
-                    const u32x4g h8 = *(const u32x4g*)&Bh[buf][(ni * 32 + li) * HB_LD + kk * 16 + lh * 8];
-                    acc[ni] = mfma16<DT>(a[kk], h8, acc[ni]);
-                    if (SPLIT) {
-                        const u32x4g l8 = *(const u32x4g*)&Bl[buf][(ni * 32 + li) * HB_LD + kk * 16 + lh * 8];
-                        acc[ni] = mfma16<DT>(a[kk], l8, acc[ni]);
-                    }
-                }
-            }
-        };
-        fetch_a(abuf[0], 0);
-        fetch_a(abuf[1], 1);
-        fetch_b(0);
-        __syncthreads();              // the previous row tile's last chunk has been read by every wave
-        store_b(0);
-        if (nks > 1) fetch_b(1);
-        for (int ks = 0; ks < nks; ks += 3) {
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                if (ks + j < nks) {                        // block-uniform
-                    fetch_a(abuf[(j + 2) % 3], ks + j + 2);
-                    step(abuf[j], ks + j);
-                }
-            }
-        }
-        float rn2[16];
-        if (p.l2) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long long row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                rn2[r] = p.n2[row < p.n ? row : p.n - 1];
-            }
-        }
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const int q = qt * HB_N + ni * 32 + li;
-            float key[16];
-            float best = -__builtin_huge_valf();
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                key[r] = p.l2 ? 2.f * acc[ni][r] - rn2[r] : acc[ni][r];
-                best = fmaxf(best, key[r]);
-            }
-            if (__any(best > thr[ni])) {                   // almost never: one test per 32 x 32 tile
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const long long row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (key[r] > thr[ni] && row < p.n) {
-                        const int pos = atomicAdd(&p.cnt[q], 1);
-                        if (pos < p.cap) { p.cand_s[(size_t)q * p.cap + pos] = key[r]; p.cand_t[(size_t)q * p.cap + pos] = row; }
-                        else p.lost[q] = 1;
-                    }
-                }
-            }
-        }
-    }
-}
-
-// Wide-tile kernel for more than one query tile.  Measured on the 128 x 128 kernel above: with the
-// 16-bit MFMA rate the bound is not load latency but bytes per flop, of LDS (a 64 x 64 wave tile
-// reads 1 KiB of fragments per MFMA, the LDS peak at full MFMA rate) and of L2 (the query operand
-// is re-read for every 128 rows).  Here a workgroup of 8 waves owns 256 rows x 256 queries and each
-// wave 128 x 64 (128 accumulator registers): 0.75 KiB of fragments per MFMA and half the query
-// traffic per row.  One workgroup per CU, so the LDS tile is double-buffered (one barrier per
-// k-step) and two k-steps of operands ride in registers across tile boundaries.
-constexpr int WB_M = 256, WB_N = 256, WB_K = 32, WB_LD = WB_K + 8;    // LDS row = 40 halfs = 80 bytes
-
-template <int DT, bool SPLIT>
-__global__ void __launch_bounds__(512, 1)
-gemm16_wide_kernel(Gemm16Params p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned short wsm[];
-    unsigned short* As = wsm;                                  // [2][WB_M * WB_LD]
-    unsigned short* Bh = As + 2 * WB_M * WB_LD;                // [2][WB_N * WB_LD]
-    unsigned short* Bl = Bh + 2 * WB_N * WB_LD;                // [2][WB_N * WB_LD] (SPLIT only)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 2, wn = wave & 3;
-    const int li = lane & 31, lh = lane >> 5;
-    const int qt = blockIdx.y;
-    const int nks = (p.dpad + WB_K - 1) / WB_K;
-    const int d8 = p.dpad >> 3;
-
-    // staging map: 16-byte chunk f = tid + 512 * i, i < 2: tile row f / 4, chunk f % 4 of the k-step
-    int srow[2], sc[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) { const int f = tid + 512 * i; srow[i] = f >> 2; sc[i] = f & 3; }
-    const unsigned short* qh[2];
-    const unsigned short* ql[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int q = qt * WB_N + srow[i];
-        if (q > p.nq - 1) q = p.nq - 1;
-        qh[i] = p.Qhi + (size_t)q * p.ldq;
-        ql[i] = SPLIT ? p.Qlo + (size_t)q * p.ldq : nullptr;
-    }
-    float thr[2];
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int q = qt * WB_N + wn * 64 + ni * 32 + li;
-        thr[ni] = (q < p.nq) ? p.thr[q] : __builtin_huge_valf();
-    }
-
-    // p.ntiles counts 256-row tiles here (tile0 = 0, stride 1: the full pass)
-    const long long my_tiles = (p.ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
-    const long long total = my_tiles * nks;
-    const long long padded = (total + 1) / 2 * 2;
-
-    u32x4g ra[2][2], rh[2][2], rl[2][2];
-    long long f_tile = blockIdx.x;
-    int f_ks = 0;
-    long long f_left = total;
-    auto fetch = [&](int u) {
-        const bool live = f_left > 0;
-        const long long row0 = f_tile * WB_M;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            long long r = row0 + srow[i];
-            if (r > p.n - 1) r = p.n - 1;
-            const int c8 = f_ks * (WB_K / 8) + sc[i];
-            const bool ok = live && c8 < d8;
-            const int c = ok ? c8 * 8 : 0;
-            const unsigned short* xa = live ? p.X + (size_t)r * p.ldx + c : (const unsigned short*)g_zero16;
-            ra[u][i] = __builtin_nontemporal_load((const u32x4g*)xa);
-            rh[u][i] = *(const u32x4g*)(ok ? qh[i] + c : (const unsigned short*)g_zero16);
-            if (SPLIT) rl[u][i] = *(const u32x4g*)(ok ? ql[i] + c : (const unsigned short*)g_zero16);
-        }
-        --f_left;
-        if (++f_ks == nks) { f_ks = 0; f_tile += gridDim.x; }
-    };
-    fetch(0);
-    fetch(1);
-
-    f32x16 acc[4][2];
-    long long c_tile = blockIdx.x;
-    int c_ks = 0;
-    for (long long s0 = 0; s0 < padded; s0 += 2) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            // every wave finished reading buffer u (two k-steps ago) before it passed the last barrier
-            unsigned short* Au = As + u * (WB_M * WB_LD);
-            unsigned short* Hu = Bh + u * (WB_N * WB_LD);
-            unsigned short* Lu = Bl + u * (WB_N * WB_LD);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                *(u32x4g*)&Au[srow[i] * WB_LD + sc[i] * 8] = ra[u][i];
-                *(u32x4g*)&Hu[srow[i] * WB_LD + sc[i] * 8] = rh[u][i];
-                if (SPLIT) *(u32x4g*)&Lu[srow[i] * WB_LD + sc[i] * 8] = rl[u][i];
-            }
-            fetch(u);
-            __syncthreads();
-            if (c_ks == 0) {
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-            }
-#pragma unroll
-            for (int kk = 0; kk < WB_K / 16; ++kk) {
-                u32x4g a8[4], h8[2], l8[2];
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi) a8[mi] = *(const u32x4g*)&Au[(wm * 128 + mi * 32 + li) * WB_LD + kk * 16 + lh * 8];
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    h8[ni] = *(const u32x4g*)&Hu[(wn * 64 + ni * 32 + li) * WB_LD + kk * 16 + lh * 8];
-                    if (SPLIT) l8[ni] = *(const u32x4g*)&Lu[(wn * 64 + ni * 32 + li) * WB_LD + kk * 16 + lh * 8];
-                }
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni) {
-                        acc[mi][ni] = mfma16<DT>(a8[mi], h8[ni], acc[mi][ni]);
-                        if (SPLIT) acc[mi][ni] = mfma16<DT>(a8[mi], l8[ni], acc[mi][ni]);
-                    }
-            }
-            if (++c_ks == nks) {
-                c_ks = 0;
-                // padded stages beyond the last tile multiply zeros; with one k-step per tile they
-                // complete a tile that does not exist
-                const long long row0 = c_tile * WB_M;
-                c_tile += gridDim.x;
-                if (row0 >= p.n) continue;
-                const long long left = p.n - row0;
-                const int nloc = left < WB_M ? (int)left : WB_M;
-                const int q0 = qt * WB_N + wn * 64 + li;
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi) {
-                    const int lr0 = wm * 128 + mi * 32 + 4 * lh;     // this lane's rows: lr0 + (r&3) + 8*(r>>2)
-                    float rn2[16];
-                    if (p.l2) {
-                        const float* n2p = p.n2 + row0;                 // row0 < n here
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int o = lr0 + (r & 3) + 8 * (r >> 2);
-                            rn2[r] = n2p[o < nloc ? o : 0];
-                        }
-                    }
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            float key = acc[mi][ni][r];
-                            if (p.l2) key = 2.f * key - rn2[r];
-                            const int lr = lr0 + (r & 3) + 8 * (r >> 2);
-                            if (__builtin_expect(key > thr[ni] && lr < nloc, 0)) {
-                                int lro = lr, q = q0 + ni * 32;
-                                asm volatile("" : "+v"(lro), "+v"(q));
-                                const int pos = atomicAdd(&p.cnt[q], 1);
-                                if (pos < p.cap) { p.cand_s[(size_t)q * p.cap + pos] = key; p.cand_t[(size_t)q * p.cap + pos] = row0 + lro; }
-                                else p.lost[q] = 1;
-                            }
-                        }
-                    }
-                }
-            }
-        }
-    }
-}
-
-template <int DT, bool SPLIT>
-static hipError_t launch_wide(const Gemm16Params& p, int nq, int n_cu, hipStream_t st) {
-    const size_t lds = (size_t)(SPLIT ? 6 : 4) * WB_M * WB_LD * sizeof(unsigned short);
-    static bool allowed = false;
-    if (!allowed) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm16_wide_kernel<DT, SPLIT>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        allowed = true;
-    }
-    const int qtiles = (nq + WB_N - 1) / WB_N;
-    long long gx = (long long)n_cu / qtiles;                  // one workgroup per CU
-    gx = gx / 8 * 8;                                          // query tiles of one row range share an XCD
-    if (gx < 8) gx = 8;
-    if (gx > p.ntiles) gx = p.ntiles;
-    hipLaunchKernelGGL((gemm16_wide_kernel<DT, SPLIT>), dim3((unsigned)gx, (unsigned)qtiles), dim3(512), lds, st, p);
-    return hipGetLastError();
 }
 
 // fp32 tables on the 16-bit matrix unit.  The fast pass only has to be accurate to the bound the
@@ -1168,21 +819,21 @@ hipError_t launch_gemm32s(const TableView& t, const unsigned short* qhi, const u
     return split ? launch_gemm32s_mode<VDB_F16, 1>(p, nq, n_cu, st) : launch_gemm32s_mode<VDB_F16, 2>(p, nq, n_cu, st);
 }
 
-// 0 = choose by shape, 1 = streaming kernel, 11 = LDS-staged tile kernel, 12 = wide-tile kernel,
-// 13 = 256-row kernel shared with the fp32 tables
-static int g_gemm16_variant = 0;
-void set_gemm16_variant(int v) { g_gemm16_variant = v; }
-
+// One threshold pass over a 16-bit table: the first pass (`dense`: every score of the leading rows
+// is kept, slot = row) on the small kernel above, every other pass on the kernel shared with the
+// fp32 tables, which visits every tile_stride-th row tile.
 hipError_t launch_gemm16_thresh(const TableView& t, const unsigned short* qhi, const unsigned short* qlo, int qstride,
                                 int split, int nq, int dpad, const float* thr,
-                                long long tile0, long long tile_stride, long long ntiles,
+                                long long tile_stride, long long ntiles,
                                 float* cand_s, long long* cand_t, int* cnt, int* lost, int cap, int dense,
                                 int n_cu, hipStream_t st) {
     if (ntiles <= 0) return hipSuccess;
+    if (!dense)
+        return launch_gemm32s(t, qhi, qlo, qstride, split, nq, dpad, thr, tile_stride, cand_s, cand_t, cnt, lost, cap, n_cu, st);
     Gemm16Params p;
     p.X = (const unsigned short*)t.rows; p.n2 = t.n2; p.Qhi = qhi; p.Qlo = qlo; p.thr = thr; p.n = t.n; p.nq = nq;
     p.dpad = dpad; p.ldq = qstride; p.ldx = t.m * 8; p.l2 = t.metric == VDB_METRIC_L2 ? 1 : 0;
-    p.tile0 = tile0; p.tile_stride = tile_stride; p.ntiles = ntiles;
+    p.tile0 = 0; p.tile_stride = tile_stride; p.ntiles = ntiles;
     p.cand_s = cand_s; p.cand_t = cand_t; p.cnt = cnt; p.lost = lost; p.cap = cap;
     const int qtiles = (nq + HB_N - 1) / HB_N;
     long long gx = (2LL * n_cu) / qtiles;                                       // two workgroups per CU
@@ -1190,39 +841,13 @@ hipError_t launch_gemm16_thresh(const TableView& t, const unsigned short* qhi, c
     if (gx < 8) gx = 8;
     if (gx > ntiles) gx = ntiles;
     const dim3 grid((unsigned)gx, (unsigned)qtiles), block(256);
-    // measured on 20M x 768: the tile kernel wins with an unsplit query up to two query tiles, the
-    // streaming kernel with more query tiles or a split query (twice the MFMA work per row byte)
-    // Full passes (every row tile), measured on 20M x 768 (these kernels run at the speed of their LDS
-    // fragment reads): a split query up to 64 queries takes the 256-row kernel shared with the fp32
-    // tables (32- and 64-query tiles: 9.8 ms against 13.3 ms at 8 queries); more than 128 queries the
-    // wide-tile kernel; otherwise the 128 x 128 tile kernel (unsplit) or the streaming kernel (split).
-    const bool full = tile0 == 0 && tile_stride == 1 && ntiles == (t.n + HB_M - 1) / HB_M;
-    if (!dense && full && ((g_gemm16_variant == 0 && split && nq <= 64) || g_gemm16_variant == 13))
-        return launch_gemm32s(t, qhi, qlo, qstride, split, nq, dpad, thr, 1, cand_s, cand_t, cnt, lost, cap, n_cu, st);
-    if (!dense && full && nq > HB_N && (g_gemm16_variant == 0 || g_gemm16_variant == 12)) {
-        Gemm16Params w = p;
-        w.ntiles = (t.n + WB_M - 1) / WB_M;
-        if (t.dt == VDB_BF16) return split ? launch_wide<VDB_BF16, true>(w, nq, n_cu, st) : launch_wide<VDB_BF16, false>(w, nq, n_cu, st);
-        return split ? launch_wide<VDB_F16, true>(w, nq, n_cu, st) : launch_wide<VDB_F16, false>(w, nq, n_cu, st);
+    if (t.dt == VDB_BF16) {
+        if (split) hipLaunchKernelGGL((gemm16_dense_kernel<VDB_BF16, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((gemm16_dense_kernel<VDB_BF16, false>), grid, block, 0, st, p);
+    } else {
+        if (split) hipLaunchKernelGGL((gemm16_dense_kernel<VDB_F16, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((gemm16_dense_kernel<VDB_F16, false>), grid, block, 0, st, p);
     }
-    const bool stream = g_gemm16_variant == 1 || (g_gemm16_variant == 0 && split);
-    if (stream && !dense) {
-        if (t.dt == VDB_BF16) {
-            if (split) hipLaunchKernelGGL((gemm16_stream_kernel<VDB_BF16, true>), grid, block, 0, st, p);
-            else hipLaunchKernelGGL((gemm16_stream_kernel<VDB_BF16, false>), grid, block, 0, st, p);
-        } else {
-            if (split) hipLaunchKernelGGL((gemm16_stream_kernel<VDB_F16, true>), grid, block, 0, st, p);
-            else hipLaunchKernelGGL((gemm16_stream_kernel<VDB_F16, false>), grid, block, 0, st, p);
-        }
-        return hipGetLastError();
-    }
-    // ring depth 1: deeper rings measured no faster (the kernel is bound by LDS and L2 bandwidth,
-    // not by load latency) and cost registers
-#define VDB_G16(DTV, SP) do { if (dense) hipLaunchKernelGGL((gemm16_thresh_kernel<DTV, SP, 1, true>), grid, block, 0, st, p); \
-                               else hipLaunchKernelGGL((gemm16_thresh_kernel<DTV, SP, 1, false>), grid, block, 0, st, p); } while (0)
-    if (t.dt == VDB_BF16) { if (split) VDB_G16(VDB_BF16, true); else VDB_G16(VDB_BF16, false); }
-    else { if (split) VDB_G16(VDB_F16, true); else VDB_G16(VDB_F16, false); }
-#undef VDB_G16
     return hipGetLastError();
 }
 

@@ -366,7 +366,7 @@ static int search_gemm_path(const TableView& tv, const SelGeom& g, int dpad, int
         unsigned short* qhi = (unsigned short*)ws.q16.p;
         unsigned short* qlo = (half || s32) ? qhi + (size_t)nqc * qstride : nullptr;
         auto gemm = [&](const TableView& v, const float* thr, long long stride, long long tiles, int dense) -> hipError_t {
-            if (half) return launch_gemm16_thresh(v, qhi, qlo, qstride, split, nqi, dpad, thr, 0, stride, tiles, cs, ct, cnt, lost, GEMM_CAP, dense, G.n_cu, st);
+            if (half) return launch_gemm16_thresh(v, qhi, qlo, qstride, split, nqi, dpad, thr, stride, tiles, cs, ct, cnt, lost, GEMM_CAP, dense, G.n_cu, st);
             return launch_gemm_thresh(v, qprep, nqi, dpad, thr, 0, stride, tiles, cs, ct, cnt, lost, GEMM_CAP, dense, G.n_cu, st);
         };
         VDB_HIP(launch_prep_query(q_dev + (size_t)q0 * tv.d, nqi, tv.d, dpad, tv.metric, qprep, qinfo, ne, st));
@@ -604,7 +604,6 @@ int vdb_set_option(const char* key, double value) {
     else if (k == "gemm32_split") G.tune_gemm32s = value < 0 ? 0 : value > 2 ? 2 : (int)value;
     else if (k == "gemm_split_bf16") G.tune_split_bf16 = value != 0;
     else if (k == "gemm32s_threads") set_gemm32s_threads((int)value);
-    else if (k == "gemm16_variant") set_gemm16_variant((int)value);
     else return fail(VDB_EINVAL, "unknown option: " + k);
     set_scan_tune(G.tune_nt, G.tune_waves, G.tune_bpc, G.tune_contig);
     return VDB_OK;

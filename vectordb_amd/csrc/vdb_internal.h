@@ -95,10 +95,9 @@ hipError_t launch_gemm_thresh(const TableView& t, const float* qprep, int nq, in
                               int n_cu, hipStream_t st);
 hipError_t launch_gemm16_thresh(const TableView& t, const unsigned short* qhi, const unsigned short* qlo, int qstride,
                                 int split, int nq, int dpad, const float* thr,
-                                long long tile0, long long tile_stride, long long ntiles,
+                                long long tile_stride, long long ntiles,
                                 float* cand_s, long long* cand_t, int* cnt, int* lost, int cap, int dense,
                                 int n_cu, hipStream_t st);
-void set_gemm16_variant(int v);
 void set_gemm32s_threads(int v);
 hipError_t launch_gemm32s(const TableView& t, const unsigned short* qhi, const unsigned short* qlo, int qstride,
                           int split, int nq, int dpad, const float* thr, long long tile_stride,
