@@ -288,6 +288,17 @@ def main() -> None:
                     line["roofline"].update({"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                              "frac": achieved / HBM_PEAK_GBS, "bytes_per_launch": bytes_per_launch,
                                              "algorithmic_tflops": tf})
+            try:
+                with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+                    pmc = json.load(fh).get("%s|rows_per_gpu=%d|dim=%d|dtype=%s|nq=%d" % (
+                        line["roofline"]["kernel"], n_local, args.dim, args.dtype, nq_launch))
+                if pmc and not args.opt:
+                    # HBM bytes per launch of the full pass (own --pmc FETCH_SIZE run): the query tiles of
+                    # one row range share the rows through L2, so this stays near one read of the table
+                    line["roofline"]["traffic"] = pmc["hbm_read_bytes_per_launch"]
+                    line["roofline"]["traffic_source"] = pmc["source"]
+            except (OSError, ValueError):
+                pass
         if world == 1 and args.cpu_seconds > 0 and args.nq == 1:
             line["cpu_baseline"] = cpu_baseline(args.rows, args.dim, args.k, args.metric, args.cpu_seconds)
         print(json.dumps(line), flush=True)

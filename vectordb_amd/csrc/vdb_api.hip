@@ -428,12 +428,20 @@ static int search_core(Table& t, int64_t nq, const float* q_dev, int k, long lon
     bool gemm = nq >= G.use_blas_threshold && tv.n >= 65536 && g.K <= 256 && G.tune_gemm != 0;
     if (gemm) {
         // Small tables: a batched pass has a fixed cost (threshold passes, flat finalize) that a
-        // few scans undercut.  Both estimates are fits of measured times (seconds; row bytes B).
+        // few scans undercut.  Both estimates are fits of measured times (seconds; row bytes B):
+        // a batched pass reads the rows once at about 6.1 TB/s and multiplies at about 5e14
+        // multiply-adds per second on the 16-bit matrix unit (times the products per term).
         const double B = (double)tv.n * tv.m * 16.0;
-        const double pass_rate = tv.dt == VDB_F32 ? (nq <= 32 ? 5.0e12 : nq <= 64 ? 4.2e12 : 3.8e12)
-                                                  : ((tv.dt == VDB_BF16 ? G.tune_split_bf16 : G.tune_split_f16) ? (nq <= 64 ? 3.2e12 : 2.3e12) : 4.0e12);
         const double est_scan = 60e-6 + (double)nq * (20e-6 + B / 6.5e12);
-        const double est_gemm = 270e-6 + (double)((nq + 127) / 128) * B / pass_rate;
+        double est_gemm;
+        if (tv.dt == VDB_F32 && G.tune_gemm32s == 0) {
+            const double pass_rate = nq <= 32 ? 5.0e12 : nq <= 64 ? 4.2e12 : 3.8e12;      // fp32 MFMA kernel
+            est_gemm = 270e-6 + (double)((nq + 127) / 128) * B / pass_rate;
+        } else {
+            const double products = tv.dt == VDB_F32 ? (G.tune_gemm32s == 1 ? 3.0 : 1.0)
+                                                     : ((tv.dt == VDB_BF16 ? G.tune_split_bf16 : G.tune_split_f16) ? 2.0 : 1.0);
+            est_gemm = 270e-6 + B / 6.1e12 + products * (double)tv.n * t.dpad * (double)nq / 5.0e14;
+        }
         if (est_scan < est_gemm) gemm = false;
     }
     if (gemm) G.batched_queries += nq;
