@@ -1,5 +1,8 @@
-// Batched-query path: scores[rows, queries] = X . Q^T as an fp32 MFMA GEMM whose epilogue keeps
-// only the scores that beat a per-query threshold.  The score matrix never reaches HBM.
+// Batched-query path: scores[rows, queries] = X . Q^T as an MFMA GEMM whose epilogue keeps only
+// the scores that beat a per-query threshold.  The score matrix never reaches HBM.  Three kernels:
+// gemm32s_kernel (16-bit MFMA; every pass but the first, every table type), and the two small
+// kernels of the first threshold pass, gemm_thresh_kernel (fp32 MFMA, also the gemm32_split=0 mode
+// of fp32 tables) and gemm16_dense_kernel (16-bit tables).
 //
 // Selection without in-kernel lists: a threshold tau_q that is known to be at or below the K-th
 // best score of query q lets the epilogue drop almost every score with one compare and append the
@@ -9,7 +12,7 @@
 // two thousand candidates per query out of millions of rows.  If a candidate array overflows
 // (rows ordered adversarially), the query is flagged and answered by the exact pass instead.
 //
-// Tile: 128 rows x 128 queries x 32 k per workgroup of four waves (2 x 2); each wave owns
+// gemm_thresh_kernel: 128 rows x 128 queries x 32 k per workgroup of four waves (2 x 2); each wave owns
 // 64 x 64 as 2 x 2 MFMA tiles of v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate in
 // k order).  Operand tiles are staged through registers into LDS rows padded by 16 bytes
 // (conflict-free 16-byte fragment reads); the loads of the next k-step are issued before the
@@ -468,12 +471,14 @@ gemm16_dense_kernel(Gemm16Params p) {
     }
 }
 
-// fp32 tables on the 16-bit matrix unit.  The fast pass only has to be accurate to the bound the
-// certificate uses, so a row value x is presented as bf16 hi + lo (hi = rne(x), lo = rne(x - hi),
-// converted in registers on the way to LDS) and the query likewise; three products are accumulated,
-// xh*qh + xh*ql + xl*qh, leaving a relative error of 3 * 2^-16 per term against 16 x the fp32 MFMA
-// rate / 3.  A workgroup of 8 waves owns 256 rows x 128 queries (64 x 64 per wave), LDS tiles are
-// double-buffered, two k-steps of operands ride in registers across tile boundaries.
+// The kernel of every pass but the first, for every table type, on the 16-bit matrix unit.  A fast
+// key only has to be accurate to the bound the finalize step uses, which re-scores every candidate
+// within twice that bound of the k-th best key; so fp32 rows are rounded to bf16 in registers on the
+// way to LDS and the query likewise (one product per term, relative error 2^-8), or both are
+// presented as hi + lo (hi = rne(x), lo = rne(x - hi)) with three products xh*qh + xh*ql + xl*qh
+// (3 * 2^-16); 16-bit rows go in as stored.  A workgroup of 8 waves owns 256 rows x 32..256 queries,
+// LDS tiles are double-buffered with one barrier per k-step, two or four k-steps of operands ride
+// in registers across tile boundaries.
 constexpr int SB_K = 32, SB_LD = SB_K + 8;     // LDS row = 40 halfs = 80 bytes
 typedef __bf16 bf16x2g __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2g __attribute__((ext_vector_type(2)));
