@@ -479,7 +479,11 @@ gemm16_dense_kernel(Gemm16Params p) {
 // (3 * 2^-16); 16-bit rows go in as stored.  A workgroup of 8 waves owns 256 rows x 32..256 queries,
 // LDS tiles are double-buffered with one barrier per k-step, two or four k-steps of operands ride
 // in registers across tile boundaries.
-constexpr int SB_K = 32, SB_LD = SB_K + 8;     // LDS row = 40 halfs = 80 bytes
+// Elements per k-step of a tile shape: 32, and 64 for the narrow tiles over 16-bit rows.  Their
+// passes are bound by reading the rows, and a row tile fetched in pieces of 128 instead of 64
+// contiguous bytes per row reads faster (20 M x 768 fp16: 5.76 -> 5.28 ms at 2 queries, 6.79 ->
+// 6.09 ms at 64); fp32 rows already come in 128-byte pieces and measured no gain from 256.
+constexpr int gemm32s_kstep(int nb, int mode) { return (nb <= 2 && (mode == 1 || mode == 2)) ? 64 : 32; }
 typedef __bf16 bf16x2g __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2g __attribute__((ext_vector_type(2)));
 
@@ -492,7 +496,7 @@ struct Gemm32sParams {
     long long    n;
     int          nq;
     int          dpad;           // elements per row (multiple of 4 for fp32 rows, of 8 for 16-bit rows)
-    int          qstride;        // halfs per query row: a multiple of 32 (whole k-steps), >= dpad
+    int          qstride;        // halfs per query row: a multiple of 64 (whole k-steps of every tile shape), >= dpad
     int          ldx;
     int          l2;
     long long    ntiles;         // 256-row tiles visited: tile t * tile_stride, t < ntiles
@@ -546,41 +550,44 @@ gemm32s_kernel(Gemm32sParams p) {
     constexpr bool F32ROWS = MODE == 0 || MODE == 3;
     constexpr bool ALO = MODE == 0;                // rows have a lo part
     constexpr bool BLO = MODE == 0 || MODE == 1;   // queries have a lo part
-    constexpr int NA = F32ROWS ? 4 : 2;            // 16-byte row chunks staged per thread and k-step
-    constexpr int CPR = F32ROWS ? 8 : 4;           // 16-byte chunks per tile row and k-step
-    constexpr int EPC = F32ROWS ? 4 : 8;           // elements per chunk
-    constexpr int RD = NB >= 4 ? 2 : 4;            // k-steps of operands in registers (narrow tiles have
+    constexpr int KS = gemm32s_kstep(NB, MODE);
+    constexpr int LD = KS + 8;                     // LDS row in halfs: 80 or 144 bytes, conflict-free b128 reads
+    constexpr int EPC = F32ROWS ? 4 : 8;           // elements per 16-byte chunk
+    constexpr int CPR = KS / EPC;                  // 16-byte chunks per tile row and k-step
+    constexpr int NA = TM * CPR / NT;              // 16-byte row chunks staged per thread and k-step
+    constexpr int QPC = KS / 8;                    // 16-byte chunks per query and k-step
+    constexpr int RD = (NB >= 4 || KS == 64) ? 2 : 4;   // k-steps of operands in registers (narrow tiles have
                                                    // little MFMA time per step to cover the load latency)
     constexpr int TN = 32 * NB;                    // queries per tile
     constexpr int NI = NB == 8 ? 4 : NB == 4 ? 2 : 1;   // 32-query blocks per wave
-    constexpr int QCH = TN * 4 > NT ? TN * 4 / NT : 1;   // 16-byte query chunks staged per thread and k-step
+    constexpr int QCH = TN * QPC > NT ? TN * QPC / NT : 1;   // 16-byte query chunks staged per thread and k-step
     constexpr int RDB = QCH >= 4 ? 1 : RD;         // k-steps of query chunks in registers (they come from L2)
     constexpr int MI = NB == 1 ? 1 : 2;            // 32-row blocks per wave
     constexpr int WN = NB / NI;                    // waves across the queries
     extern __shared__ __attribute__((aligned(16))) unsigned short ssm[];
-    unsigned short* Ah = ssm;                                  // [2][TM * SB_LD]
-    unsigned short* Al = Ah + 2 * TM * SB_LD;                  // rows with a lo part only
-    unsigned short* Bh = Al + (ALO ? 2 * TM * SB_LD : 0);      // [2][TN * SB_LD]
-    unsigned short* Bl = Bh + 2 * TN * SB_LD;                  // queries with a lo part only
+    unsigned short* Ah = ssm;                                  // [2][TM * LD]
+    unsigned short* Al = Ah + 2 * TM * LD;                  // rows with a lo part only
+    unsigned short* Bh = Al + (ALO ? 2 * TM * LD : 0);      // [2][TN * LD]
+    unsigned short* Bl = Bh + 2 * TN * LD;                  // queries with a lo part only
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
     const int qt = blockIdx.y;
-    const int nks = (p.dpad + SB_K - 1) / SB_K;
+    const int nks = (p.dpad + KS - 1) / KS;
     const int dch = p.dpad / EPC;                  // 16-byte chunks per row
 
     // staging: row chunks f = tid + NT * i (i < NA): tile row f / CPR, chunk f % CPR;
-    //          query chunks g = tid + NT * j (j < QCH): tile query g / 4, 8-half chunk g % 4
+    //          query chunks g = tid + NT * j (j < QCH): tile query g / QPC, 8-half chunk g % QPC
     int arow[NA], ac[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) { const int f = tid + NT * i; arow[i] = f / CPR; ac[i] = f % CPR; }
-    const int brow = tid >> 2, bc = tid & 3;       // chunk j: tile query brow + (NT / 4) * j
-    const bool bstage = tid < TN * 4;              // threads that stage a query chunk
+    const int brow = tid / QPC, bc = tid % QPC;    // chunk j: tile query brow + (NT / QPC) * j
+    const bool bstage = tid < TN * QPC;            // threads that stage a query chunk
     const unsigned short* qh[QCH];
     const unsigned short* ql[QCH];
 #pragma unroll
     for (int j = 0; j < QCH; ++j) {
-        int qb = qt * TN + (bstage ? brow + (NT / 4) * j : 0);
+        int qb = qt * TN + (bstage ? brow + (NT / QPC) * j : 0);
         if (qb > p.nq - 1) qb = p.nq - 1;
         qh[j] = p.Qhi + (size_t)qb * p.qstride;
         ql[j] = p.Qlo + (size_t)qb * p.qstride;
@@ -623,8 +630,8 @@ gemm32s_kernel(Gemm32sParams p) {
     // the k-steps
     int b_ks = 0;
     auto fetch_q = [&](int v) {
-        const int c8 = b_ks * (SB_K / 8) + bc;     // < qstride / 8: query rows are padded to whole k-steps
-        if (TN * 4 >= NT || bstage) {
+        const int c8 = b_ks * QPC + bc;     // < qstride / 8: query rows are padded to whole k-steps
+        if (TN * QPC >= NT || bstage) {
 #pragma unroll
             for (int j = 0; j < QCH; ++j) {
                 rh[v][j] = *(const u32x4g*)(qh[j] + c8 * 8);
@@ -647,29 +654,29 @@ gemm32s_kernel(Gemm32sParams p) {
     // stage(w, b): operands of register set w go to LDS buffer b (fp32 rows converted on the way),
     // then the set is refilled with the operands RD k-steps ahead
     auto stage = [&](int w, int b) {
-        unsigned short* Ahw = Ah + b * (TM * SB_LD);
-        unsigned short* Alw = Al + b * (TM * SB_LD);
-        unsigned short* Bhw = Bh + b * (TN * SB_LD);
-        unsigned short* Blw = Bl + b * (TN * SB_LD);
+        unsigned short* Ahw = Ah + b * (TM * LD);
+        unsigned short* Alw = Al + b * (TM * LD);
+        unsigned short* Bhw = Bh + b * (TN * LD);
+        unsigned short* Blw = Bl + b * (TN * LD);
         const int wb = RDB == 1 ? 0 : w;            // query register set
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             if constexpr (MODE == 0) {
                 u32x2g h2, l2;
                 split4_bf16(__builtin_bit_cast(f32x4, ra[w][i]), h2, l2);
-                *(u32x2g*)&Ahw[arow[i] * SB_LD + ac[i] * 4] = h2;
-                *(u32x2g*)&Alw[arow[i] * SB_LD + ac[i] * 4] = l2;
+                *(u32x2g*)&Ahw[arow[i] * LD + ac[i] * 4] = h2;
+                *(u32x2g*)&Alw[arow[i] * LD + ac[i] * 4] = l2;
             } else if constexpr (MODE == 3) {
-                *(u32x2g*)&Ahw[arow[i] * SB_LD + ac[i] * 4] = round4_bf16(__builtin_bit_cast(f32x4, ra[w][i]));
+                *(u32x2g*)&Ahw[arow[i] * LD + ac[i] * 4] = round4_bf16(__builtin_bit_cast(f32x4, ra[w][i]));
             } else {
-                *(u32x4g*)&Ahw[arow[i] * SB_LD + ac[i] * 8] = ra[w][i];
+                *(u32x4g*)&Ahw[arow[i] * LD + ac[i] * 8] = ra[w][i];
             }
         }
-        if (TN * 4 >= NT || bstage) {
+        if (TN * QPC >= NT || bstage) {
 #pragma unroll
             for (int j = 0; j < QCH; ++j) {
-                *(u32x4g*)&Bhw[(brow + (NT / 4) * j) * SB_LD + bc * 8] = rh[wb][j];
-                if (BLO) *(u32x4g*)&Blw[(brow + (NT / 4) * j) * SB_LD + bc * 8] = rl[wb][j];
+                *(u32x4g*)&Bhw[(brow + (NT / QPC) * j) * LD + bc * 8] = rh[wb][j];
+                if (BLO) *(u32x4g*)&Blw[(brow + (NT / QPC) * j) * LD + bc * 8] = rl[wb][j];
             }
         }
         // queries first: with one k-step of them in registers they are needed a stage before the
@@ -690,10 +697,10 @@ gemm32s_kernel(Gemm32sParams p) {
     for (long long s0 = 0; s0 < padded; s0 += RD) {
 #pragma unroll
         for (int u = 0; u < RD; ++u) {
-            const unsigned short* Ahu = Ah + (u & 1) * (TM * SB_LD);
-            const unsigned short* Alu = Al + (u & 1) * (TM * SB_LD);
-            const unsigned short* Bhu = Bh + (u & 1) * (TN * SB_LD);
-            const unsigned short* Blu = Bl + (u & 1) * (TN * SB_LD);
+            const unsigned short* Ahu = Ah + (u & 1) * (TM * LD);
+            const unsigned short* Alu = Al + (u & 1) * (TM * LD);
+            const unsigned short* Bhu = Bh + (u & 1) * (TN * LD);
+            const unsigned short* Blu = Bl + (u & 1) * (TN * LD);
             __syncthreads();
             if (c_ks == 0) {
 #pragma unroll
@@ -704,18 +711,18 @@ gemm32s_kernel(Gemm32sParams p) {
                         for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
             }
 #pragma unroll
-            for (int kk = 0; kk < SB_K / 16; ++kk) {
-                if (kk == SB_K / 32) stage((u + 1) % RD, (u + 1) & 1);
+            for (int kk = 0; kk < KS / 16; ++kk) {
+                if (kk == KS / 32) stage((u + 1) % RD, (u + 1) & 1);
                 u32x4g ah[MI], al[MI], bh[NI], bl[NI];
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
-                    ah[mi] = *(const u32x4g*)&Ahu[((wm * MI + mi) * 32 + li) * SB_LD + kk * 16 + lh * 8];
-                    if (ALO) al[mi] = *(const u32x4g*)&Alu[((wm * MI + mi) * 32 + li) * SB_LD + kk * 16 + lh * 8];
+                    ah[mi] = *(const u32x4g*)&Ahu[((wm * MI + mi) * 32 + li) * LD + kk * 16 + lh * 8];
+                    if (ALO) al[mi] = *(const u32x4g*)&Alu[((wm * MI + mi) * 32 + li) * LD + kk * 16 + lh * 8];
                 }
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
-                    bh[ni] = *(const u32x4g*)&Bhu[((wn * NI + ni) * 32 + li) * SB_LD + kk * 16 + lh * 8];
-                    if (BLO) bl[ni] = *(const u32x4g*)&Blu[((wn * NI + ni) * 32 + li) * SB_LD + kk * 16 + lh * 8];
+                    bh[ni] = *(const u32x4g*)&Bhu[((wn * NI + ni) * 32 + li) * LD + kk * 16 + lh * 8];
+                    if (BLO) bl[ni] = *(const u32x4g*)&Blu[((wn * NI + ni) * 32 + li) * LD + kk * 16 + lh * 8];
                 }
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
@@ -773,7 +780,7 @@ gemm32s_kernel(Gemm32sParams p) {
 template <int NB, int DT, int MODE, int NT>
 static hipError_t launch_gemm32s_nb(const Gemm32sParams& p0, int nq, int n_cu, hipStream_t st) {
     constexpr int TM = NT / 2;
-    const size_t lds = (size_t)2 * ((MODE == 0 ? 2 : 1) * TM + (MODE == 0 || MODE == 1 ? 2 : 1) * 32 * NB) * SB_LD * sizeof(unsigned short);
+    const size_t lds = (size_t)2 * ((MODE == 0 ? 2 : 1) * TM + (MODE == 0 || MODE == 1 ? 2 : 1) * 32 * NB) * (gemm32s_kstep(NB, MODE) + 8) * sizeof(unsigned short);
     static bool allowed = false;
     if (!allowed) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm32s_kernel<NB, DT, MODE, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -337,7 +337,7 @@ static int search_gemm_path(const TableView& tv, const SelGeom& g, int dpad, int
     // term (relative error 3 * 2^-16) when gemm32_split is 1
     const bool s32 = !half && G.tune_gemm32s != 0;
     const int s32split = G.tune_gemm32s == 1 ? 1 : 0;
-    const int qstride = (dpad + 31) / 32 * 32;       // 16-bit query rows: zero padded to whole k-steps of the kernels
+    const int qstride = (dpad + 63) / 64 * 64;       // 16-bit query rows: zero padded to whole k-steps of the kernels
     FlatBound fb;
     fb.dd_mult = s32 ? (s32split ? 3.0 : 1.0) : ((half && split) ? 2.0 : 1.0);
     fb.extra_rel = s32 ? (s32split ? 5.0e-5 : 3.92e-3)
