@@ -757,17 +757,28 @@ gemm32s_kernel(Gemm32sParams p) {
                     }
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni) {
+                        // one compare for the 16 scores of a lane first: a lane meets a candidate in
+                        // about one tile out of 300
+                        float best = -__builtin_huge_valf();
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             float key = acc[mi][ni][r];
                             if (p.l2) key = 2.f * key - rn2[r];
-                            const int lr = lr0 + (r & 3) + 8 * (r >> 2);
-                            if (__builtin_expect(key > thr[ni] && lr < nloc, 0)) {
-                                int lro = lr, q = q0 + ni * 32;
-                                asm volatile("" : "+v"(lro), "+v"(q));
-                                const int pos = atomicAdd(&p.cnt[q], 1);
-                                if (pos < p.cap) { p.cand_s[(size_t)q * p.cap + pos] = key; p.cand_t[(size_t)q * p.cap + pos] = row0 + lro; }
-                                else p.lost[q] = 1;
+                            best = fmaxf(best, key);
+                        }
+                        if (__builtin_expect(best > thr[ni], 0)) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                float key = acc[mi][ni][r];
+                                if (p.l2) key = 2.f * key - rn2[r];
+                                const int lr = lr0 + (r & 3) + 8 * (r >> 2);
+                                if (key > thr[ni] && lr < nloc) {
+                                    int lro = lr, q = q0 + ni * 32;
+                                    asm volatile("" : "+v"(lro), "+v"(q));
+                                    const int pos = atomicAdd(&p.cnt[q], 1);
+                                    if (pos < p.cap) { p.cand_s[(size_t)q * p.cap + pos] = key; p.cand_t[(size_t)q * p.cap + pos] = row0 + lro; }
+                                    else p.lost[q] = 1;
+                                }
                             }
                         }
                     }
