@@ -277,7 +277,7 @@ kth_threshold_kernel(const float* __restrict__ cand_s, long long stride, const i
 
 hipError_t launch_kth_threshold(const float* cand_s, long long stride, const int* cnt, long long count_all,
                                 int cap, int K, const float* thr_in, float* thr_out, int nq, hipStream_t st) {
-    hipLaunchKernelGGL(kth_threshold_kernel, dim3((unsigned)nq), dim3(256), 0, st,
+    hipLaunchKernelGGL(kth_threshold_kernel, dim3((unsigned)nq), dim3(1024), 0, st,
                        cand_s, stride, cnt, count_all, cap, K, thr_in, thr_out);
     return hipGetLastError();
 }
