@@ -65,6 +65,27 @@ def test_synthetic_rows_match_oracle_bitwise(engine, table_name):
     assert np.array_equal(buf.cpu().numpy().view(np.uint32), O.synth_rows(9, 11, 70, 33).view(np.uint32))
 
 
+def test_append_of_more_rows_than_one_launch_holds(engine, table_name):
+    """70 M rows appended by one call: one wave per row would need a grid of more than 2^32
+    work-items, which is not launched whole, so the append runs in launches of 2^24 rows.  Rows on
+    both sides of every launch boundary, the first and the last row hold their own values and ids,
+    and a query that is a copy of the last row finds it."""
+    n, d = 70_000_000, 4
+    engine.create_table(table_name, d, _lib.METRIC_L2, _lib.F32)
+    engine.reserve(table_name, n)
+    engine.insert_synthetic(table_name, n, seed=3, first_row=0)
+    assert engine.count(table_name) == n
+    probes = [0, (1 << 24) - 1, 1 << 24, (1 << 25) - 1, 1 << 25, 3 << 24, (1 << 26) - 1, 1 << 26, n - 2]
+    for r in probes:
+        got, ids = engine.fetch_rows(table_name, r, 2)
+        assert np.array_equal(got.view(np.uint32), O.synth_rows(3, r, 2, d).view(np.uint32)), r
+        assert ids.tolist() == [r, r + 1]
+    q = O.synth_rows(3, n - 1, 1, d)
+    ids, sc, cnt = engine.search(table_name, q, 1)
+    assert cnt[0] == 1 and sc[0, 0] == 0.0
+    assert np.array_equal(O.synth_rows(3, int(ids[0, 0]), 1, d), q)      # a row with exactly these values
+
+
 def test_synthetic_cosine_table_is_normalised_like_the_oracle(engine, table_name):
     engine.create_table(table_name, 768, _lib.METRIC_COSINE, _lib.F32)
     engine.insert_synthetic(table_name, 2000, seed=0, first_row=100)
@@ -585,6 +606,7 @@ def test_batched_fp32_with_large_magnitudes_and_ties(engine, table_name, split):
     ("cosine", "f32", 10_000_000, 768, 10, 1024),     # config 3: batch 1024
     ("ip", "bf16", 12_500_000, 128, 100, 3),          # config 4: one shard of 100M / 8
     ("l2", "f16", 20_000_000, 768, 10, 256),          # config 5
+    ("l2", "f16", 125_000_000, 768, 10, 256),         # config 5, one whole per-GPU shard of 1B / 8: 192 GB
 ])
 def test_full_size_properties(engine, table_name, metric, dtype, n, d, k, nq):
     """BASELINE's own sizes, through size-independent properties: scores are the canonical scores of

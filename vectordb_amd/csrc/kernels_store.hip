@@ -106,16 +106,25 @@ hipError_t launch_append(char* rows, long long* ids, float* n2, float* max_n2,
                          long long row0, long long n, int d, int m, int dt, int metric,
                          const float* raw, const long long* raw_ids,
                          uint64_t seed, long long synth_first_row, hipStream_t st) {
-    if (n <= 0) return hipSuccess;
-    const dim3 block(256), grid((unsigned)((n + 3) / 4));
-#define VDB_APPEND(DT)                                                                          \
-    hipLaunchKernelGGL((append_kernel<DT>), grid, block, 0, st, rows, ids, n2, max_n2, row0, n, \
-                       d, m, metric, raw, raw_ids, seed, synth_first_row)
-    if (dt == VDB_F32) VDB_APPEND(VDB_F32);
-    else if (dt == VDB_BF16) VDB_APPEND(VDB_BF16);
-    else VDB_APPEND(VDB_F16);
+    // One wave per row: a launch holds at most 2^24 rows, because a grid of 2^32 work-items or more
+    // is not launched whole (125 M rows in one launch filled 58 M of them and reported no error).
+    const long long chunk = 1ll << 24;
+    for (long long c0 = 0; c0 < n; c0 += chunk) {
+        const long long nc = n - c0 < chunk ? n - c0 : chunk;
+        const dim3 block(256), grid((unsigned)((nc + 3) / 4));
+        const float* raw_c = raw ? raw + (size_t)c0 * d : nullptr;
+        const long long* ids_c = raw_ids ? raw_ids + c0 : nullptr;
+#define VDB_APPEND(DT)                                                                               \
+        hipLaunchKernelGGL((append_kernel<DT>), grid, block, 0, st, rows, ids, n2, max_n2, row0 + c0, nc, \
+                           d, m, metric, raw_c, ids_c, seed, synth_first_row + c0)
+        if (dt == VDB_F32) VDB_APPEND(VDB_F32);
+        else if (dt == VDB_BF16) VDB_APPEND(VDB_BF16);
+        else VDB_APPEND(VDB_F16);
 #undef VDB_APPEND
-    return hipGetLastError();
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 __global__ void __launch_bounds__(256)
