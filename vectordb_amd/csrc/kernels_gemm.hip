@@ -483,7 +483,10 @@ gemm16_dense_kernel(Gemm16Params p) {
 // passes are bound by reading the rows, and a row tile fetched in pieces of 128 instead of 64
 // contiguous bytes per row reads faster (20 M x 768 fp16: 5.76 -> 5.28 ms at 2 queries, 6.79 ->
 // 6.09 ms at 64); fp32 rows already come in 128-byte pieces and measured no gain from 256.
-constexpr int gemm32s_kstep(int nb, int mode) { return (nb <= 2 && (mode == 1 || mode == 2)) ? 64 : 32; }
+// The 256-query tile over 16-bit rows takes 64 as well, with one k-step of operands in registers
+// instead of two: half the barriers for the same bytes in flight (20 M x 768 fp16, 256 queries:
+// 10.1 -> 9.3 ms); with fp32 rows the same change spills and loses (19.8 -> 21.2 ms).
+constexpr int gemm32s_kstep(int nb, int mode) { return ((nb <= 2 || nb == 8) && (mode == 1 || mode == 2)) ? 64 : 32; }
 typedef __bf16 bf16x2g __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2g __attribute__((ext_vector_type(2)));
 
@@ -556,7 +559,7 @@ gemm32s_kernel(Gemm32sParams p) {
     constexpr int CPR = KS / EPC;                  // 16-byte chunks per tile row and k-step
     constexpr int NA = TM * CPR / NT;              // 16-byte row chunks staged per thread and k-step
     constexpr int QPC = KS / 8;                    // 16-byte chunks per query and k-step
-    constexpr int RD = (NB >= 4 || KS == 64) ? 2 : 4;   // k-steps of operands in registers (narrow tiles have
+    constexpr int RD = (NB == 8 && KS == 64) ? 1 : (NB >= 4 || KS == 64) ? 2 : 4;   // k-steps of operands in registers (narrow tiles have
                                                    // little MFMA time per step to cover the load latency)
     constexpr int TN = 32 * NB;                    // queries per tile
     constexpr int NI = NB == 8 ? 4 : NB == 4 ? 2 : 1;   // 32-query blocks per wave
@@ -601,7 +604,8 @@ gemm32s_kernel(Gemm32sParams p) {
 
     const long long my_tiles = (p.ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
     const long long total = my_tiles * nks;
-    const long long padded = (total + RD - 1) / RD * RD;
+    constexpr int UN = RD < 2 ? 2 : RD;            // stages per trip of the unrolled loop (LDS buffers alternate)
+    const long long padded = (total + UN - 1) / UN * UN;
 
     u32x4g ra[RD][NA];                             // raw 16 bytes: 4 fp32 or 8 16-bit values
     u32x4g rh[RDB][QCH], rl[RDB][QCH];
@@ -694,9 +698,9 @@ gemm32s_kernel(Gemm32sParams p) {
     f32x16 acc[MI][NI];
     long long c_tile = blockIdx.x;
     int c_ks = 0;
-    for (long long s0 = 0; s0 < padded; s0 += RD) {
+    for (long long s0 = 0; s0 < padded; s0 += UN) {
 #pragma unroll
-        for (int u = 0; u < RD; ++u) {
+        for (int u = 0; u < UN; ++u) {
             const unsigned short* Ahu = Ah + (u & 1) * (TM * LD);
             const unsigned short* Alu = Al + (u & 1) * (TM * LD);
             const unsigned short* Bhu = Bh + (u & 1) * (TN * LD);
