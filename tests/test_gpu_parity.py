@@ -121,6 +121,35 @@ def test_search_parity_16bit(engine, table_name, metric, d, dtype):
     _check(engine, table_name, stored, ids, q, 10, m)
 
 
+def test_largest_dimension_scan_and_batched(engine, table_name):
+    """dim = 16384, the largest the library accepts (64 KiB per fp32 row): three queries through the
+    batched path (512 k-steps per tile), two of them again as single scans; a 16-bit table of the same
+    dimension through the scan.  Rows are generated on the device and, for the oracle, by the C
+    restatement of the same generator."""
+    from oracle import oracle_c as OC
+    d, n = 16384, 65_600
+    engine.create_table(table_name, d, _lib.METRIC_L2, _lib.F32)
+    engine.insert_synthetic(table_name, n, seed=7, first_row=0)
+    stored = O.prepare_store(OC.synth_rows(7, 0, n, d), O.L2, O.F32)
+    ids = np.arange(n, dtype=np.int64)
+    q = OC.synth_rows(8, 0, 3, d)
+    q[2] = stored[40_000]
+    before = engine.stats()[2]
+    _check(engine, table_name, stored, ids, q, 10, O.L2)
+    assert engine.stats()[2] - before == 3
+    engine.set_option("gemm_path", 0)
+    try:
+        _check(engine, table_name, stored, ids, q[1:], 10, O.L2)
+    finally:
+        engine.set_option("gemm_path", 1)
+    engine.drop_table(table_name)
+    n16 = 3_000
+    engine.create_table(table_name, d, _lib.METRIC_COSINE, _lib.BF16)
+    engine.insert_synthetic(table_name, n16, seed=9, first_row=0)
+    stored16 = O.prepare_store(OC.synth_rows(9, 0, n16, d), O.COSINE, O.BF16)
+    _check(engine, table_name, stored16, np.arange(n16, dtype=np.int64), q[:2], 10, O.COSINE)
+
+
 @pytest.mark.parametrize("n", [1, 2, 9, 31, 32, 33, 63, 64, 65, 1000, 4097])
 @pytest.mark.parametrize("k", [1, 10, 100])
 def test_search_parity_sizes(engine, table_name, n, k):

@@ -581,9 +581,9 @@ gemm32s_kernel(Gemm32sParams p) {
 
     // staging: row chunks f = tid + NT * i (i < NA): tile row f / CPR, chunk f % CPR;
     //          query chunks g = tid + NT * j (j < QCH): tile query g / QPC, 8-half chunk g % QPC
-    int arow[NA], ac[NA];
-#pragma unroll
-    for (int i = 0; i < NA; ++i) { const int f = tid + NT * i; arow[i] = f / CPR; ac[i] = f % CPR; }
+    // NT is a multiple of CPR: chunk i of a thread lies NT / CPR rows below chunk 0, same column
+    static_assert(NT % CPR == 0, "staging map");
+    const int arow0 = tid / CPR, ac0 = tid % CPR;
     const int brow = tid / QPC, bc = tid % QPC;    // chunk j: tile query brow + (NT / QPC) * j
     const bool bstage = tid < TN * QPC;            // threads that stage a query chunk
     const unsigned short* qh[QCH];
@@ -620,9 +620,9 @@ gemm32s_kernel(Gemm32sParams p) {
         const long long row0 = f_tile * p.tile_stride * TM;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            long long r = row0 + arow[i];
+            long long r = row0 + (arow0 + (NT / CPR) * i);
             if (r > p.n - 1) r = p.n - 1;
-            const int ch = f_ks * CPR + ac[i];
+            const int ch = f_ks * CPR + ac0;
             const char* xa = (const char*)p.X + ((size_t)r * p.ldx + (ch < dch ? ch * EPC : 0)) * (F32ROWS ? 4 : 2);
             // rows stream once past a single query tile; several query tiles of one row range run
             // on one XCD side by side and meet in its L2, so their loads leave the lines there
@@ -668,12 +668,12 @@ gemm32s_kernel(Gemm32sParams p) {
             if constexpr (MODE == 0) {
                 u32x2g h2, l2;
                 split4_bf16(__builtin_bit_cast(f32x4, ra[w][i]), h2, l2);
-                *(u32x2g*)&Ahw[arow[i] * LD + ac[i] * 4] = h2;
-                *(u32x2g*)&Alw[arow[i] * LD + ac[i] * 4] = l2;
+                *(u32x2g*)&Ahw[(arow0 + (NT / CPR) * i) * LD + ac0 * 4] = h2;
+                *(u32x2g*)&Alw[(arow0 + (NT / CPR) * i) * LD + ac0 * 4] = l2;
             } else if constexpr (MODE == 3) {
-                *(u32x2g*)&Ahw[arow[i] * LD + ac[i] * 4] = round4_bf16(__builtin_bit_cast(f32x4, ra[w][i]));
+                *(u32x2g*)&Ahw[(arow0 + (NT / CPR) * i) * LD + ac0 * 4] = round4_bf16(__builtin_bit_cast(f32x4, ra[w][i]));
             } else {
-                *(u32x4g*)&Ahw[arow[i] * LD + ac[i] * 8] = ra[w][i];
+                *(u32x4g*)&Ahw[(arow0 + (NT / CPR) * i) * LD + ac0 * 8] = ra[w][i];
             }
         }
         if (TN * QPC >= NT || bstage) {
