@@ -79,3 +79,49 @@ def test_http_routes_over_the_engine(engine):
     assert http.get("/checkintegrity").get_data(as_text=True) == "All ok"
     assert http.get("/deletedb?dbname=" + name).get_data(as_text=True) == "Table deleted"
     assert not engine.has_table(name)
+
+
+def test_concurrent_lookups_are_merged_and_stay_exact(engine):
+    """Sixteen threads call search_vectors at once, the way one-thread-per-request HTTP serving
+    does.  Calls that arrive while a search runs are merged into batched calls; every caller still
+    gets the oracle's answer for its own query."""
+    import threading
+    from milvus import MetricType, Milvus
+    m = Milvus()
+    assert m.connect().OK()
+    name = "coalesced"
+    m.delete_table(name)
+    n, d, k, nthreads, rounds = 200_000, 96, 10, 16, 4
+    assert m.create_table({"table_name": name, "dimension": d, "metric_type": MetricType.COSINE}).OK()
+    rows = cases.make_rows("synth", 71, n, d)
+    ids = cases.make_ids("hash", 71, n)
+    engine.insert(name, rows, ids)
+    stored = O.prepare_store(rows, O.COSINE)
+    q = cases.make_queries("synth", 71, nthreads * rounds, d, rows)
+    want = cases.oracle_search(stored, ids, q, k, O.COSINE)
+    got = [None] * len(q)
+    co = m._eng().coalescer                     # the shim's process-wide engine object carries it
+    assert co is not None
+    calls0, req0, batched0 = co.calls, co.requests, engine.stats()[2]
+    barrier = threading.Barrier(nthreads)
+
+    def worker(t):
+        for r in range(rounds):
+            i = r * nthreads + t
+            barrier.wait()
+            got[i] = m.search_vectors(table_name=name, query_records=[q[i].tolist()], top_k=k, nprobe=10)
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(nthreads)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    for i, (wi, ws) in enumerate(want):
+        status, results = got[i]
+        assert status.OK() and len(results) == 1
+        assert [r.id for r in results[0]] == [int(x) for x in wi]
+        assert [np.float32(r.distance) for r in results[0]] == list(ws)
+    assert co.requests - req0 == len(q)
+    assert co.calls - calls0 < len(q)                    # some calls carried several callers
+    assert engine.stats()[2] - batched0 > 0              # and went through the batched path
+    assert m.delete_table(name).OK()

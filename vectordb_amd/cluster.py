@@ -26,6 +26,7 @@ from typing import Any, Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import _lib
+from .coalesce import SearchCoalescer
 from .config import EngineConfig, load_config
 from .milvus import MetricType, QueryResult, Status
 
@@ -75,6 +76,7 @@ class ClusterMilvus:
         self._lock = threading.Lock()                       # one request at a time per pipe set
         self._metric: Dict[str, int] = {}
         self._rows: Dict[str, List[int]] = {}                # rows per shard, for least-filled placement
+        self._coalescer = SearchCoalescer(self._search_arrays) if self._config.coalesce_searches else None
 
     # -- plumbing ---------------------------------------------------------------------------
     @staticmethod
@@ -252,29 +254,44 @@ class ClusterMilvus:
     add_vectors = insert
 
     # -- search ----------------------------------------------------------------------------
-    def search_vectors(self, table_name: str, top_k: int, nprobe: int = 0,
-                       query_records: Optional[Sequence[Sequence[float]]] = None,
-                       query_ranges=None) -> Tuple[Status, List[List[QueryResult]]]:
+    def _search_arrays(self, table_name: str, q: np.ndarray, k: int):
+        """All shards at once, merged on the host: (ids [nq, k], scores [nq, k], counts [nq])."""
         with self._lock:
             bad = self._need() or self._table_state(table_name)
             if bad:
-                return bad, []
-            q = np.asarray(query_records, dtype=np.float32)
-            if q.ndim != 2:
-                return Status(_lib.EINVAL, "query_records must be a list of equal-length vectors"), []
-            k = int(top_k)
+                raise _lib.VdbError(bad.code, bad.message)
             replies = self._call_all("search_arrays", table_name, q, k)
             st = self._first_failure(replies)
             if not st.OK():
-                return st, []
+                raise _lib.VdbError(st.code, st.message)
             l2 = self._metric[table_name] == int(MetricType.L2)
-            results = []
-            for qi in range(q.shape[0]):
-                ids = np.concatenate([r[2][qi, :int(r[4][qi])] for r in replies])
-                sc = np.concatenate([r[3][qi, :int(r[4][qi])] for r in replies])
-                order = np.lexsort((ids, sc if l2 else -sc))[:k]
-                results.append([QueryResult(int(ids[j]), float(sc[j])) for j in order])
-            return Status(), results
+        nq = q.shape[0]
+        out_ids = np.full((nq, k), -1, dtype=np.int64)
+        out_sc = np.full((nq, k), np.inf if l2 else -np.inf, dtype=np.float32)
+        out_cnt = np.zeros((nq,), dtype=np.int32)
+        for qi in range(nq):
+            ids = np.concatenate([r[2][qi, :int(r[4][qi])] for r in replies])
+            sc = np.concatenate([r[3][qi, :int(r[4][qi])] for r in replies])
+            order = np.lexsort((ids, sc if l2 else -sc))[:k]
+            out_ids[qi, :len(order)] = ids[order]
+            out_sc[qi, :len(order)] = sc[order]
+            out_cnt[qi] = len(order)
+        return out_ids, out_sc, out_cnt
+
+    def search_vectors(self, table_name: str, top_k: int, nprobe: int = 0,
+                       query_records: Optional[Sequence[Sequence[float]]] = None,
+                       query_ranges=None) -> Tuple[Status, List[List[QueryResult]]]:
+        q = np.asarray(query_records, dtype=np.float32)
+        if q.ndim != 2:
+            return Status(_lib.EINVAL, "query_records must be a list of equal-length vectors"), []
+        try:
+            # concurrent callers are merged into one call to the workers (vectordb_amd/coalesce.py)
+            fn = self._coalescer.search if self._coalescer is not None else self._search_arrays
+            ids, sc, cnt = fn(table_name, q, int(top_k))
+        except _lib.VdbError as exc:
+            return Status(exc.code, exc.message), []
+        return Status(), [[QueryResult(int(ids[i, j]), float(sc[i, j])) for j in range(int(cnt[i]))]
+                          for i in range(q.shape[0])]
 
     search = search_vectors
 

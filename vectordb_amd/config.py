@@ -7,8 +7,11 @@ in `raw` so that an existing file loads unchanged.
 
   engine_config.use_blas_threshold (server_config.yaml:36)  batch size from which batched
       queries use the MFMA GEMM path instead of the per-query scan.  The reference's file says 20
-      (the external engine's CPU BLAS crossover); here one batched pass costs 1.4 to 3 scans and the
-      library compares both estimates per call, so the built-in default is 2 and a deployment that keeps the reference's file should lower it
+      (the external engine's CPU BLAS crossover); here one batched pass over up to 128 queries costs
+      about 1.2 scans and the library compares both estimates per call, so the built-in default is 2
+      and a deployment that keeps the reference's file should lower it
+  engine_config.coalesce_searches (an addition, default true)  searches that arrive while another one
+      is running are merged into one batched call (vectordb_amd/coalesce.py)
   gpu_resource_config.enable (:41)           must be true: there is no CPU engine
   gpu_resource_config.cache_capacity (:42)   GB of HBM the tables may occupy (0 = no cap)
   gpu_resource_config.search_resources (:43-44)  `gpuN` entries: the shard set; a process binds
@@ -33,6 +36,7 @@ _GPU_RE = re.compile(r"^gpu(\d+)$")
 class EngineConfig:
     use_blas_threshold: int = 2          # this engine's measured crossover; the file's value wins when present
     gpu_search_threshold: int = 1000
+    coalesce_searches: bool = True
     gpu_enable: bool = True
     cache_capacity_gb: float = 0.0
     search_resources: List[int] = field(default_factory=lambda: [0])
@@ -67,6 +71,8 @@ def parse_config(doc: Optional[Dict[str, Any]]) -> EngineConfig:
         cfg.use_blas_threshold = int(eng["use_blas_threshold"])
     if "gpu_search_threshold" in eng:
         cfg.gpu_search_threshold = int(eng["gpu_search_threshold"])
+    if "coalesce_searches" in eng:
+        cfg.coalesce_searches = bool(eng["coalesce_searches"])
     if "enable" in gpu:
         cfg.gpu_enable = bool(gpu["enable"])
     if "cache_capacity" in gpu and gpu["cache_capacity"] is not None:
