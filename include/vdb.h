@@ -80,7 +80,9 @@ int vdb_shutdown(void);
  * "gemm_split_bf16" / "gemm_split_f16" (1 = the fp32 query goes in as hi + lo parts of the table's
  * type, two products per term; default 0: rounded once),
  * "gemm32s_threads" (workgroup shape of the 256-query tile: 512 = 8 waves over 256 rows (default),
- * 256 = 4 waves over 128 rows, two workgroups per CU). */
+ * 256 = 4 waves over 128 rows, two workgroups per CU).
+ * Host calls: "coalesce_host" (1 = blocking vdb_search calls that arrive from other threads while one
+ * is running are merged into one batched search, see vdb_search; default 1). */
 int vdb_set_option(const char* key, double value);
 const char* vdb_last_error(void);
 
@@ -134,7 +136,12 @@ int vdb_load_table(const char* name, const char* path);
  * queries: [nq, dim] fp32.  Outputs, per query q: out_counts[q] = min(k, rows) hits, best first,
  * ties ordered by id ascending; out_ids[q*k + i], out_scores[q*k + i]; unused slots hold id -1.
  * Scores: IP / COSINE similarity (larger first) or squared L2 distance (smaller first).
- * nprobe of the reference call has no counterpart: the scan is exhaustive. */
+ * nprobe of the reference call has no counterpart: the scan is exhaustive.
+ * vdb_search blocks.  The reference serves every request on its own thread against one engine
+ * handle (app.py:11-12, 186-190), so calls arrive side by side: a call that arrives while another
+ * one is running waits for it, and the next call to run takes along every waiting call on the same
+ * table with the same k (up to 1024 queries) as one batched search.  Results are the same as for
+ * separate calls; a lone caller is never delayed. */
 int vdb_search(const char* name, int64_t nq, const float* queries, int k,
                int64_t* out_ids, float* out_scores, int32_t* out_counts);
 int vdb_search_dev(const char* name, int64_t nq, const float* queries_dev, int k,

@@ -83,8 +83,8 @@ def test_http_routes_over_the_engine(engine):
 
 def test_concurrent_lookups_are_merged_and_stay_exact(engine):
     """Sixteen threads call search_vectors at once, the way one-thread-per-request HTTP serving
-    does.  Calls that arrive while a search runs are merged into batched calls; every caller still
-    gets the oracle's answer for its own query."""
+    does.  Calls that arrive while a search runs are merged into batched calls inside vdb_search;
+    every caller still gets the oracle's answer for its own query, with merging on and off."""
     import threading
     from milvus import MetricType, Milvus
     m = Milvus()
@@ -100,9 +100,6 @@ def test_concurrent_lookups_are_merged_and_stay_exact(engine):
     q = cases.make_queries("synth", 71, nthreads * rounds, d, rows)
     want = cases.oracle_search(stored, ids, q, k, O.COSINE)
     got = [None] * len(q)
-    co = m._eng().coalescer                     # the shim's process-wide engine object carries it
-    assert co is not None
-    calls0, req0, batched0 = co.calls, co.requests, engine.stats()[2]
     barrier = threading.Barrier(nthreads)
 
     def worker(t):
@@ -111,17 +108,28 @@ def test_concurrent_lookups_are_merged_and_stay_exact(engine):
             barrier.wait()
             got[i] = m.search_vectors(table_name=name, query_records=[q[i].tolist()], top_k=k, nprobe=10)
 
-    threads = [threading.Thread(target=worker, args=(t,)) for t in range(nthreads)]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join(timeout=120)
-    for i, (wi, ws) in enumerate(want):
-        status, results = got[i]
-        assert status.OK() and len(results) == 1
-        assert [r.id for r in results[0]] == [int(x) for x in wi]
-        assert [np.float32(r.distance) for r in results[0]] == list(ws)
-    assert co.requests - req0 == len(q)
-    assert co.calls - calls0 < len(q)                    # some calls carried several callers
-    assert engine.stats()[2] - batched0 > 0              # and went through the batched path
+    for merged in (1, 0):
+        engine.set_option("coalesce_host", merged)
+        try:
+            before = engine.stats()
+            threads = [threading.Thread(target=worker, args=(t,)) for t in range(nthreads)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join(timeout=120)
+            after = engine.stats()
+        finally:
+            engine.set_option("coalesce_host", 1)
+        for i, (wi, ws) in enumerate(want):
+            status, results = got[i]
+            assert status.OK() and len(results) == 1
+            assert [r.id for r in results[0]] == [int(x) for x in wi]
+            assert [np.float32(r.distance) for r in results[0]] == list(ws)
+            got[i] = None
+        assert after[0] - before[0] == len(q)
+        # merged: some calls carried several callers and went through the batched path
+        assert (after[2] - before[2] > 0) == bool(merged)
+    # a failing merged call reports to every caller: the table is gone
     assert m.delete_table(name).OK()
+    status, results = m.search_vectors(table_name=name, query_records=[q[0].tolist()], top_k=k, nprobe=10)
+    assert not status.OK() and results == []

@@ -13,7 +13,6 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vectordb_amd import _lib  # noqa: E402
-from vectordb_amd.coalesce import SearchCoalescer  # noqa: E402
 from vectordb_amd.milvus import Milvus  # noqa: E402
 
 
@@ -37,7 +36,7 @@ def main():
     torch.cuda.synchronize()
     queries = [row.tolist() for row in qd.cpu().numpy()]
     for merged in (False, True):
-        eng.coalescer = SearchCoalescer(eng.search) if merged else None
+        eng.set_option("coalesce_host", 1 if merged else 0)
         for nt in [int(x) for x in args.threads.split(",")]:
             stop = time.perf_counter() + args.seconds
             counts = [0] * nt
@@ -57,9 +56,8 @@ def main():
             for th in threads:
                 th.join()
             dt = time.perf_counter() - t0
-            calls = eng.coalescer.calls if merged else sum(counts)
-            print("merged=%d threads=%3d: %8.1f QPS  (%d queries in %d engine calls, %.2f s)"
-                  % (merged, nt, sum(counts) / dt, sum(counts), calls, dt), flush=True)
+            print("merged=%d threads=%3d: %8.1f QPS  (%d queries, %.2f s)" % (merged, nt, sum(counts) / dt, sum(counts), dt), flush=True)
+    eng.set_option("coalesce_host", 1)
     eng.drop_table(name)
 
 

@@ -11,7 +11,8 @@ in `raw` so that an existing file loads unchanged.
       about 1.2 scans and the library compares both estimates per call, so the built-in default is 2
       and a deployment that keeps the reference's file should lower it
   engine_config.coalesce_searches (an addition, default true)  searches that arrive while another one
-      is running are merged into one batched call (vectordb_amd/coalesce.py)
+      is running are merged into one batched call (inside vdb_search; in front of the workers of the
+      multi-GPU client: vectordb_amd/coalesce.py)
   gpu_resource_config.enable (:41)           must be true: there is no CPU engine
   gpu_resource_config.cache_capacity (:42)   GB of HBM the tables may occupy (0 = no cap)
   gpu_resource_config.search_resources (:43-44)  `gpuN` entries: the shard set; a process binds

@@ -4,6 +4,7 @@
 
 #include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -67,6 +68,7 @@ struct Table {
     size_t bytes_per_row() const { return (size_t)m * 16 + sizeof(long long) + sizeof(float); }
 };
 
+struct HostReq;
 struct Global {
     std::mutex mu;                       // registry, workspaces, options
     bool inited = false;
@@ -76,7 +78,7 @@ struct Global {
     std::vector<std::unique_ptr<Workspace>> free_ws;
     long long* d_counters = nullptr;
     // options
-    int use_blas_threshold = 2;          // a batched pass costs 1.4 (fp32) to 3 (bf16) scans: see search_core
+    int use_blas_threshold = 2;          // a batched pass over up to 128 queries costs about 1.2 scans: see search_core
     double cache_capacity_gb = 0.0;
     double insert_buffer_gb = 1.0;
     size_t table_bytes = 0;
@@ -97,6 +99,12 @@ struct Global {
     hipEvent_t chain_ev[16] = {};
     int chain_head = -1;
     hipStream_t chain_last = nullptr;
+    // merging of concurrent blocking host searches (guarded by co_mu; see vdb_search)
+    std::mutex co_mu;
+    std::condition_variable co_cv;
+    bool co_busy = false;
+    std::vector<HostReq*> co_pending;
+    int coalesce_host = 1;
 };
 static Global G;
 
@@ -607,6 +615,7 @@ int vdb_set_option(const char* key, double value) {
     else if (k == "scan_contiguous") G.tune_contig = value != 0;
     else if (k == "scan_serialize") { std::lock_guard<std::mutex> cl(G.chain_mu); G.scan_serialize = value != 0; }
     else if (k == "scan_sample") G.tune_sample = value != 0;
+    else if (k == "coalesce_host") G.coalesce_host = value != 0;
     else if (k == "gemm_path") G.tune_gemm = value != 0;
     else if (k == "gemm_split_f16") G.tune_split_f16 = value != 0;
     else if (k == "gemm32_split") G.tune_gemm32s = value < 0 ? 0 : value > 2 ? 2 : (int)value;
@@ -956,18 +965,36 @@ int vdb_search_dev(const char* name, int64_t nq, const float* queries_dev, int k
     return rc;
 }
 
-int vdb_search(const char* name, int64_t nq, const float* queries, int k,
-               int64_t* out_ids, float* out_scores, int32_t* out_counts) {
-    int rc = enter();
-    if (rc) return rc;
-    if ((rc = check_search_args(name, nq, queries, k, out_ids, out_scores, out_counts))) return rc;
-    auto t = find_table(name);
-    if (!t) return fail(VDB_ENOTFOUND, std::string("no such table: ") + name);
-    if (nq == 0) return VDB_OK;
+namespace vdb {
+// One blocking host call, possibly carrying the queries of several callers (see vdb_search).
+struct HostReq {
+    std::shared_ptr<Table> t;
+    int            k = 0;
+    int64_t        nq = 0;
+    const float*   queries = nullptr;
+    int64_t*       out_ids = nullptr;
+    float*         out_scores = nullptr;
+    int32_t*       out_counts = nullptr;
+    int            rc = VDB_OK;
+    std::string    err;
+    bool           done = false;
+};
+
+// Runs the requests of `batch` (same table, same k) as one search.  The result code and message
+// go into every request; the message is also this thread's last error.
+static void search_host_batch(std::vector<HostReq*>& batch) {
+    Table& tab = *batch[0]->t;
+    const int k = batch[0]->k;
+    int64_t nq = 0;
+    for (HostReq* r : batch) nq += r->nq;
+    int rc = VDB_OK;
     std::unique_ptr<Workspace> ws;
-    if ((rc = acquire_ws(nullptr, ws))) return rc;
+    if ((rc = acquire_ws(nullptr, ws))) {
+        for (HostReq* r : batch) { r->rc = rc; r->err = tl_error; }
+        return;
+    }
     hipStream_t st = ws->stream;
-    const size_t d = (size_t)t->dim;
+    const size_t d = (size_t)tab.dim;
     // Results leave the device as one block (ids | scores | counts) and, like the queries, pass
     // through a pinned host buffer: copies from and to pageable memory are staged by the runtime
     // one by one and cost several times the 3 KB they move.
@@ -988,21 +1015,35 @@ int vdb_search(const char* name, int64_t nq, const float* queries, int k,
         }
         char* hq = pinned ? (char*)ws->h_pin : nullptr;
         char* ho = pinned ? hq + qbytes : nullptr;
-        if (pinned) std::memcpy(hq, queries, qbytes);
-        hipError_t e = hipMemcpyAsync(ws->q_raw.p, pinned ? (const void*)hq : (const void*)queries, qbytes, hipMemcpyHostToDevice, st);
+        hipError_t e = hipSuccess;
+        if (pinned) {
+            size_t off = 0;
+            for (HostReq* r : batch) { std::memcpy(hq + off, r->queries, (size_t)r->nq * d * sizeof(float)); off += (size_t)r->nq * d * sizeof(float); }
+            e = hipMemcpyAsync(ws->q_raw.p, hq, qbytes, hipMemcpyHostToDevice, st);
+        } else {
+            size_t off = 0;
+            for (HostReq* r : batch) {
+                if (e == hipSuccess) e = hipMemcpyAsync((char*)ws->q_raw.p + off, r->queries, (size_t)r->nq * d * sizeof(float), hipMemcpyHostToDevice, st);
+                off += (size_t)r->nq * d * sizeof(float);
+            }
+        }
         if (e != hipSuccess) { rc = fail(VDB_EHIP, std::string("query upload: ") + hipGetErrorString(e)); break; }
         {
-            std::shared_lock<std::shared_mutex> tl(t->mu);
-            if (t->dropped) rc = fail(VDB_ENOTFOUND, "table was dropped");
-            else rc = search_core(*t, nq, (const float*)ws->q_raw.p, k, (long long*)o_dev,
+            std::shared_lock<std::shared_mutex> tl(tab.mu);
+            if (tab.dropped) rc = fail(VDB_ENOTFOUND, "table was dropped");
+            else rc = search_core(tab, nq, (const float*)ws->q_raw.p, k, (long long*)o_dev,
                                   (float*)(o_dev + ib), (int*)(o_dev + ib + sb), st, *ws);
             if (rc == VDB_OK) {
                 if (pinned) {
                     e = hipMemcpyAsync(ho, o_dev, obytes, hipMemcpyDeviceToHost, st);
                 } else {
-                    e = hipMemcpyAsync(out_ids, o_dev, ib, hipMemcpyDeviceToHost, st);
-                    if (e == hipSuccess) e = hipMemcpyAsync(out_scores, o_dev + ib, sb, hipMemcpyDeviceToHost, st);
-                    if (e == hipSuccess) e = hipMemcpyAsync(out_counts, o_dev + ib + sb, cb, hipMemcpyDeviceToHost, st);
+                    int64_t q0 = 0;
+                    for (HostReq* r : batch) {
+                        if (e == hipSuccess) e = hipMemcpyAsync(r->out_ids, o_dev + (size_t)q0 * k * sizeof(long long), (size_t)r->nq * k * sizeof(long long), hipMemcpyDeviceToHost, st);
+                        if (e == hipSuccess) e = hipMemcpyAsync(r->out_scores, o_dev + ib + (size_t)q0 * k * sizeof(float), (size_t)r->nq * k * sizeof(float), hipMemcpyDeviceToHost, st);
+                        if (e == hipSuccess) e = hipMemcpyAsync(r->out_counts, o_dev + ib + sb + (size_t)q0 * sizeof(int), (size_t)r->nq * sizeof(int), hipMemcpyDeviceToHost, st);
+                        q0 += r->nq;
+                    }
                 }
                 if (e == hipSuccess) e = hipStreamSynchronize(st);
                 if (e != hipSuccess) rc = fail(VDB_EHIP, std::string("result download: ") + hipGetErrorString(e));
@@ -1011,13 +1052,66 @@ int vdb_search(const char* name, int64_t nq, const float* queries, int k,
             }
         }
         if (rc == VDB_OK && pinned) {
-            std::memcpy(out_ids, ho, ib);
-            std::memcpy(out_scores, ho + ib, sb);
-            std::memcpy(out_counts, ho + ib + sb, cb);
+            int64_t q0 = 0;
+            for (HostReq* r : batch) {
+                std::memcpy(r->out_ids, ho + (size_t)q0 * k * sizeof(long long), (size_t)r->nq * k * sizeof(long long));
+                std::memcpy(r->out_scores, ho + ib + (size_t)q0 * k * sizeof(float), (size_t)r->nq * k * sizeof(float));
+                std::memcpy(r->out_counts, ho + ib + sb + (size_t)q0 * sizeof(int), (size_t)r->nq * sizeof(int));
+                q0 += r->nq;
+            }
         }
     } while (0);
     release_ws(ws, st);
-    return rc;
+    for (HostReq* r : batch) { r->rc = rc; if (rc != VDB_OK) r->err = tl_error; }
+}
+
+}  // namespace vdb
+
+// Blocking calls from several host threads are merged: one scan of the table saturates HBM, so N
+// concurrent single-query calls would take N scans one after the other, while one call with N
+// queries takes about the time of 1.2 scans on the batched path and returns the same ids and
+// scores.  There is no waiting window: the first caller runs at once; callers that arrive while
+// it runs queue up, and the next one to get the turn takes everything queued for the same table
+// and k along with it (up to 1024 queries).  Option "coalesce_host" 0 turns this off.
+int vdb_search(const char* name, int64_t nq, const float* queries, int k,
+               int64_t* out_ids, float* out_scores, int32_t* out_counts) {
+    int rc = enter();
+    if (rc) return rc;
+    if ((rc = check_search_args(name, nq, queries, k, out_ids, out_scores, out_counts))) return rc;
+    HostReq req;
+    req.t = find_table(name);
+    if (!req.t) return fail(VDB_ENOTFOUND, std::string("no such table: ") + name);
+    if (nq == 0) return VDB_OK;
+    req.k = k; req.nq = nq; req.queries = queries;
+    req.out_ids = out_ids; req.out_scores = out_scores; req.out_counts = out_counts;
+    std::vector<HostReq*> batch;
+    if (!G.coalesce_host) {
+        batch.push_back(&req);
+        search_host_batch(batch);
+        return req.rc;
+    }
+    {
+        std::unique_lock<std::mutex> lk(G.co_mu);
+        G.co_pending.push_back(&req);
+        G.co_cv.wait(lk, [&] { return req.done || !G.co_busy; });
+        if (req.done) return req.rc == VDB_OK ? VDB_OK : fail(req.rc, req.err);
+        G.co_busy = true;                         // this caller's turn
+        int64_t total = 0;
+        std::vector<HostReq*> rest;
+        for (HostReq* r : G.co_pending) {
+            if (r->t.get() == req.t.get() && r->k == k && (r == &req || total + r->nq <= 1024)) { batch.push_back(r); total += r->nq; }
+            else rest.push_back(r);
+        }
+        G.co_pending.swap(rest);
+    }
+    search_host_batch(batch);
+    {
+        std::lock_guard<std::mutex> lk(G.co_mu);
+        for (HostReq* r : batch) if (r != &req) r->done = true;
+        G.co_busy = false;
+    }
+    G.co_cv.notify_all();
+    return req.rc;
 }
 
 int vdb_merge_topk_dev(int nparts, int64_t nq, int k, int metric, const int64_t* in_ids_dev,

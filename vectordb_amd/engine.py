@@ -35,6 +35,7 @@ class Engine:
         check(self.lib.vdb_set_option(b"use_blas_threshold", float(self.config.use_blas_threshold)))
         check(self.lib.vdb_set_option(b"cache_capacity_gb", float(self.config.cache_capacity_gb)))
         check(self.lib.vdb_set_option(b"insert_buffer_size_gb", float(self.config.insert_buffer_size_gb)))
+        check(self.lib.vdb_set_option(b"coalesce_host", 1.0 if self.config.coalesce_searches else 0.0))
 
     # ---- lifecycle
     def create_table(self, name: str, dim: int, metric: int = METRIC_IP, dtype: int = F32) -> None:

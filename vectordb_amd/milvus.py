@@ -28,7 +28,6 @@ import numpy as np
 from . import _lib
 from ._lib import VdbError
 from .config import EngineConfig, load_config
-from .coalesce import SearchCoalescer
 from .engine import Engine
 
 
@@ -129,8 +128,6 @@ def _get_engine(config: Optional[EngineConfig]) -> Engine:
             rank = int(os.environ.get("LOCAL_RANK", "0"))
             device = int(os.environ.get("VDB_DEVICE", cfg.device_for_rank(rank)))
             engine = Engine(device=device, config=cfg)
-            # concurrent callers (one thread per HTTP request) share one coalescer per engine
-            engine.coalescer = SearchCoalescer(engine.search) if cfg.coalesce_searches else None
             _preload(engine, cfg)
             _engine = engine
         return _engine
@@ -282,9 +279,8 @@ class Milvus:
             q = np.asarray(query_records, dtype=np.float32)
             if q.ndim != 2:
                 raise VdbError(_lib.EINVAL, "query_records must be a list of equal-length vectors")
-            eng = self._eng()
-            merged = getattr(eng, "coalescer", None)
-            ids, scores, counts = (merged.search if merged is not None else eng.search)(table_name, q, int(top_k))
+            # concurrent callers (one thread per HTTP request) are merged inside vdb_search
+            ids, scores, counts = self._eng().search(table_name, q, int(top_k))
             results = [[QueryResult(int(ids[i, j]), float(scores[i, j])) for j in range(int(counts[i]))]
                        for i in range(q.shape[0])]
             return Status(), results
