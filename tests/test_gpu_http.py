@@ -91,14 +91,17 @@ def test_concurrent_lookups_are_merged_and_stay_exact(engine):
     assert m.connect().OK()
     name = "coalesced"
     m.delete_table(name)
-    n, d, k, nthreads, rounds = 200_000, 96, 10, 16, 4
+    from oracle import oracle_c as OC
+    # a scan of this table takes about 0.2 ms, several times the spacing of the callers' arrivals
+    n, d, k, nthreads, rounds = 3_000_000, 96, 10, 16, 4
     assert m.create_table({"table_name": name, "dimension": d, "metric_type": MetricType.COSINE}).OK()
-    rows = cases.make_rows("synth", 71, n, d)
-    ids = cases.make_ids("hash", 71, n)
-    engine.insert(name, rows, ids)
-    stored = O.prepare_store(rows, O.COSINE)
-    q = cases.make_queries("synth", 71, nthreads * rounds, d, rows)
+    engine.insert_synthetic(name, n, seed=71, first_row=0)
+    stored = O.prepare_store(OC.synth_rows(71, 0, n, d), O.COSINE)
+    ids = np.arange(n, dtype=np.int64)
+    q = OC.synth_rows(72, 0, nthreads * rounds, d)
+    q[5] = stored[123_456]
     want = cases.oracle_search(stored, ids, q, k, O.COSINE)
+    qlists = [row.tolist() for row in q]
     got = [None] * len(q)
     barrier = threading.Barrier(nthreads)
 
@@ -106,7 +109,7 @@ def test_concurrent_lookups_are_merged_and_stay_exact(engine):
         for r in range(rounds):
             i = r * nthreads + t
             barrier.wait()
-            got[i] = m.search_vectors(table_name=name, query_records=[q[i].tolist()], top_k=k, nprobe=10)
+            got[i] = m.search_vectors(table_name=name, query_records=[qlists[i]], top_k=k, nprobe=10)
 
     for merged in (1, 0):
         engine.set_option("coalesce_host", merged)
@@ -131,5 +134,5 @@ def test_concurrent_lookups_are_merged_and_stay_exact(engine):
         assert (after[2] - before[2] > 0) == bool(merged)
     # a failing merged call reports to every caller: the table is gone
     assert m.delete_table(name).OK()
-    status, results = m.search_vectors(table_name=name, query_records=[q[0].tolist()], top_k=k, nprobe=10)
+    status, results = m.search_vectors(table_name=name, query_records=[qlists[0]], top_k=k, nprobe=10)
     assert not status.OK() and results == []

@@ -736,6 +736,7 @@ gemm32s_kernel(Gemm32sParams p) {
                         if (BLO) acc[mi][ni] = mfma16<DT>(ah[mi], bl[ni], acc[mi][ni]);
                         acc[mi][ni] = mfma16<DT>(ah[mi], bh[ni], acc[mi][ni]);
                     }
+                __builtin_amdgcn_iglp_opt(0);
             }
             if (++c_ks == nks) {
                 c_ks = 0;

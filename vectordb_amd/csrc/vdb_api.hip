@@ -347,7 +347,9 @@ static int search_gemm_path(const TableView& tv, const SelGeom& g, int dpad, int
     const int s32split = G.tune_gemm32s == 1 ? 1 : 0;
     const int qstride = (dpad + 63) / 64 * 64;       // 16-bit query rows: zero padded to whole k-steps of the kernels
     FlatBound fb;
-    fb.dd_mult = s32 ? (s32split ? 3.0 : 1.0) : ((half && split) ? 2.0 : 1.0);
+    // accumulation chain in units of d: one per product, and a factor of two of margin on the
+    // matrix unit's internal summation order and rounding
+    fb.dd_mult = 2.0 * (s32 ? (s32split ? 3.0 : 1.0) : ((half && split) ? 2.0 : 1.0));
     fb.extra_rel = s32 ? (s32split ? 5.0e-5 : 3.92e-3)
                        : (!half ? 0.0 : (tv.dt == VDB_BF16 ? (split ? 1.6e-5 : 1.96e-3) : (split ? 2.5e-7 : 4.9e-4)));
     fb.extra_abs = tv.dt == VDB_F16 ? 3.0e-8 * std::sqrt((double)tv.d) : 0.0;      // fp16 subnormal steps
