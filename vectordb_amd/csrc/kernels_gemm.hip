@@ -736,6 +736,8 @@ gemm32s_kernel(Gemm32sParams p) {
                         if (BLO) acc[mi][ni] = mfma16<DT>(ah[mi], bl[ni], acc[mi][ni]);
                         acc[mi][ni] = mfma16<DT>(ah[mi], bh[ni], acc[mi][ni]);
                     }
+                // scheduling hint: interleave the LDS reads with the MFMAs of this block (2 % on the
+                // 256-query tile; variant 1 of the hint sends the compiler out of memory on this kernel)
                 __builtin_amdgcn_iglp_opt(0);
             }
             if (++c_ks == nks) {
