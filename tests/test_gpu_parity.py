@@ -445,7 +445,7 @@ def test_batched_path_matches_scan_path(engine, table_name):
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
 @pytest.mark.parametrize("metric", ["ip", "cosine", "l2"])
-@pytest.mark.parametrize("d,nq", [(96, 33), (200, 150), (768, 24)])
+@pytest.mark.parametrize("d,nq", [(96, 33), (200, 150), (768, 24), (520, 100)])
 def test_batched_gemm_path_16bit_parity(engine, table_name, metric, dtype, d, nq):
     """bf16 / fp16 tables: the batch runs on the 16-bit MFMA with the query rounded once to the
     table's type (default) or split into hi + lo parts (`gemm_split_bf16` / `gemm_split_f16`);

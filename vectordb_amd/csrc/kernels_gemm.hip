@@ -479,14 +479,14 @@ gemm16_dense_kernel(Gemm16Params p) {
 // (3 * 2^-16); 16-bit rows go in as stored.  A workgroup of 8 waves owns 256 rows x 32..256 queries,
 // LDS tiles are double-buffered with one barrier per k-step, two or four k-steps of operands ride
 // in registers across tile boundaries.
-// Elements per k-step of a tile shape: 32, and 64 for the narrow tiles over 16-bit rows.  Their
-// passes are bound by reading the rows, and a row tile fetched in pieces of 128 instead of 64
-// contiguous bytes per row reads faster (20 M x 768 fp16: 5.76 -> 5.28 ms at 2 queries, 6.79 ->
-// 6.09 ms at 64); fp32 rows already come in 128-byte pieces and measured no gain from 256.
-// The 256-query tile over 16-bit rows takes 64 as well, with one k-step of operands in registers
-// instead of two: half the barriers for the same bytes in flight (20 M x 768 fp16, 256 queries:
-// 10.1 -> 9.3 ms); with fp32 rows the same change spills and loses (19.8 -> 21.2 ms).
-constexpr int gemm32s_kstep(int nb, int mode) { return ((nb <= 2 || nb == 8) && (mode == 1 || mode == 2)) ? 64 : 32; }
+// Elements per k-step: 64 over 16-bit rows, 32 over fp32 rows.  A row tile over 16-bit rows is then
+// fetched in pieces of 128 instead of 64 contiguous bytes per row, which reads faster where the
+// pass is bound by the rows (20 M x 768 fp16: 5.76 -> 5.28 ms at 2 queries, 6.79 -> 6.09 ms at 64),
+// and halves the barriers per byte for the wide tiles (7.65 -> 6.52 ms at 128 queries, 10.1 -> 9.0 ms
+// at 256, the latter with one k-step of operands in registers instead of two).  fp32 rows already
+// come in 128-byte pieces: 256 measured no gain on the narrow tiles and spills on the 256-query tile
+// (19.8 -> 21.2 ms).
+constexpr int gemm32s_kstep(int nb, int mode) { return (mode == 1 || mode == 2) ? 64 : 32; }
 typedef __bf16 bf16x2g __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2g __attribute__((ext_vector_type(2)));
 
