@@ -20,6 +20,7 @@
 // on one XCD so that the row tile is fetched from HBM once and served from that XCD's L2.
 #include "vdb_internal.h"
 #include "select.h"
+#include "gemm_pp.h"
 
 namespace vdb {
 
@@ -919,6 +920,92 @@ hipError_t launch_split_query16(int dt, const float* qprep, int nq, int dpad, in
     if (dt == VDB_BF16) hipLaunchKernelGGL((split_query16_kernel<VDB_BF16>), dim3((unsigned)nq), dim3(256), 0, st, qprep, dpad, stride_out, hi, lo, lost);
     else hipLaunchKernelGGL((split_query16_kernel<VDB_F16>), dim3((unsigned)nq), dim3(256), 0, st, qprep, dpad, stride_out, hi, lo, lost);
     return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Ping-pong kernel (gemm_pp.h) for batches of more than 128 queries.
+// The queries go in as a tiled 16-bit image: [ceil(nq/256)][nks] blocks of 256 queries x 32 elements in
+// the LDS stage layout (pp_tiled_index), zero for queries past nq and elements past dpad; L2 tables
+// get -2q (exact: a power of two), so that the kernel accumulates ||x||^2 - 2 x.q.
+template <int DT>
+__global__ void __launch_bounds__(256)
+tile_query16_kernel(const float* __restrict__ q, int nq, int dpad, int nks, float scale,
+                    unsigned short* __restrict__ image, int* __restrict__ bad) {
+    const int qi = blockIdx.x;                     // < ceil(nq/256)*256
+    bool isbad = false;
+    for (int j = threadIdx.x; j < nks * 32; j += blockDim.x) {
+        const float x = (qi < nq && j < dpad) ? q[(size_t)qi * dpad + j] * scale : 0.f;
+        unsigned short h;
+        float hf;
+        if constexpr (DT == VDB_BF16) {
+            const __bf16 b = (__bf16)x;
+            h = __builtin_bit_cast(unsigned short, b);
+            hf = (float)b;
+        } else {
+            const _Float16 hh = (_Float16)x;
+            hf = (float)hh;
+            __builtin_memcpy(&h, &hh, 2);
+        }
+        if (!(fabsf(hf) <= 3.0e38f)) isbad = true;
+        image[pp_tiled_index(qi, j, nks)] = h;
+    }
+    if (isbad && qi < nq) bad[qi] = 1;
+}
+
+static int pp_nks(int dpad) { return (dpad + 31) / 32; }
+
+bool pp_eligible(const TableView& t, int dpad) {
+    if (!t.rows16) return false;
+    // every k-step reads 32 elements of a row: the row must hold them (mirror rows are padded with
+    // zeros; 16-bit rows qualify when their length is a whole number of k-steps)
+    return (long long)pp_nks(dpad) * 32 <= t.ld16;
+}
+
+size_t pp_query_image_bytes(int nq, int dpad) {
+    return (size_t)((nq + 255) / 256) * pp_nks(dpad) * 16384;
+}
+
+hipError_t launch_tile_query16(int dt, int l2, const float* qprep, int nq, int dpad, unsigned short* image,
+                               int* bad, hipStream_t st) {
+    const int rows = (nq + 255) / 256 * 256;
+    const float scale = l2 ? -2.f : 1.f;
+    if (dt == VDB_BF16) hipLaunchKernelGGL((tile_query16_kernel<VDB_BF16>), dim3((unsigned)rows), dim3(256), 0, st, qprep, nq, dpad, pp_nks(dpad), scale, image, bad);
+    else hipLaunchKernelGGL((tile_query16_kernel<VDB_F16>), dim3((unsigned)rows), dim3(256), 0, st, qprep, nq, dpad, pp_nks(dpad), scale, image, bad);
+    return hipGetLastError();
+}
+
+template <int DT, bool L2M>
+static hipError_t launch_gemm_pp_v(const GemmPPParams& p, int n_cu, hipStream_t st) {
+    constexpr int lds = L2M ? PP_LDS_L2 : PP_LDS_IP;
+    static bool allowed = false;
+    if (!allowed) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_pp_kernel<DT, L2M, false, 16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        allowed = true;
+    }
+    const int qtiles = (p.nq + PP_TN - 1) / PP_TN;
+    long long gx = (long long)n_cu / qtiles;       // one workgroup per CU
+    gx = gx / 8 * 8;                               // the query tiles of one row range share an XCD (and its L2)
+    if (gx < 8) gx = 8;
+    if (gx > p.ntiles) gx = p.ntiles;
+    hipLaunchKernelGGL((gemm_pp_kernel<DT, L2M, false, 16, false>), dim3((unsigned)gx, (unsigned)qtiles), dim3(512), lds, st, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm_pp(const TableView& t, const unsigned short* qimage, int nq, int dpad, const float* thr,
+                          long long tile_stride, float* cand_s, long long* cand_t, int* cnt, int* lost, int cap,
+                          int n_cu, hipStream_t st) {
+    GemmPPParams p;
+    p.X = t.rows16; p.n2 = t.n2; p.Q = qimage; p.thr = thr; p.n = t.n; p.ldx = t.ld16; p.nq = nq;
+    p.qstride = 0; p.nks = pp_nks(dpad);
+    p.tile_stride = tile_stride < 1 ? 1 : tile_stride;
+    p.ntiles = ((t.n + PP_TM - 1) / PP_TM + p.tile_stride - 1) / p.tile_stride;
+    p.cand_s = cand_s; p.cand_t = cand_t; p.cnt = cnt; p.lost = lost; p.cap = cap; p.dense = nullptr;
+    if (p.ntiles <= 0) return hipSuccess;
+    const bool l2 = t.metric == VDB_METRIC_L2;
+    const int dt = t.dt == VDB_F16 ? VDB_F16 : VDB_BF16;       // fp32 tables multiply their bf16 mirror
+    if (dt == VDB_BF16) return l2 ? launch_gemm_pp_v<VDB_BF16, true>(p, n_cu, st) : launch_gemm_pp_v<VDB_BF16, false>(p, n_cu, st);
+    return l2 ? launch_gemm_pp_v<VDB_F16, true>(p, n_cu, st) : launch_gemm_pp_v<VDB_F16, false>(p, n_cu, st);
 }
 
 }  // namespace vdb

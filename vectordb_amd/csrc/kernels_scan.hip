@@ -498,7 +498,7 @@ struct FinParams {
     const float*     flat_tau;   // [nq] every row that is not a candidate has a fast key <= tau
     const int*       flat_lost;  // [nq]
     const int*       flat_bad;   // [nq] query not representable on the batched path (may be null)
-    double           dd_mult, extra_rel, extra_abs;   // see FlatBound
+    double           dd_mult, extra_rel, extra_abs, l2_bias;   // see FlatBound
     float*           floor_out;  // lists mode, non-null: only write the K-th best fast key per query and return
 };
 
@@ -889,7 +889,8 @@ finalize_band_kernel(FinParams p) {
         const double xq = p.extra_rel * bx * bq + p.extra_abs * bx;
         double eps;
         if (!l2) eps = 1.05 * dd * u * bx * bq + xq;
-        else eps = 1.05 * u * (2.0 * dd * bx * bq + 4.0 * (bx * bx + 2.0 * bx * bq)) + 2.0 * xq + 4.0 * u * (bx + bq) * (bx + bq);
+        else eps = 1.05 * u * (2.0 * dd * bx * bq + 4.0 * (bx * bx + 2.0 * bx * bq)) + 2.0 * xq + 4.0 * u * (bx + bq) * (bx + bq)
+                   + p.l2_bias * 1.05 * u * dd * bx * bx;       // keys accumulated on top of ||x||^2: partial sums of that size
         eps = (eps + 4.0 * u * fabs(fk) + 1e-37) * 1.001;
         eps += 8.0 * u * eps;                           // keys in the band are up to 2 eps away from f_k
         band = fk - 2.0 * eps;
@@ -961,7 +962,7 @@ hipError_t launch_finalize(const TableView& t, const float* qprep, const QInfo* 
     p.out_ids = out_ids; p.out_scores = out_scores; p.out_counts = out_counts;
     p.need_exact = need_exact; p.counters = counters;
     p.flat_cnt = nullptr; p.flat_cap = 0; p.flat_tau = nullptr; p.flat_lost = nullptr; p.flat_bad = nullptr;
-    p.dd_mult = 1.0; p.extra_rel = 0.0; p.extra_abs = 0.0; p.floor_out = nullptr;
+    p.dd_mult = 1.0; p.extra_rel = 0.0; p.extra_abs = 0.0; p.l2_bias = 0.0; p.floor_out = nullptr;
     int kr = 1; while (kr < g.K) kr <<= 1;
     const size_t lds = 1088 + (size_t)g.K * 12 + (size_t)kr * 12 + (size_t)FIN_CAP * 8;
     hipError_t e = allow_lds(finalize_kernel, lds);
@@ -999,7 +1000,7 @@ hipError_t launch_finalize_flat(const TableView& t, const float* qprep, const QI
     p.out_ids = out_ids; p.out_scores = out_scores; p.out_counts = out_counts;
     p.need_exact = need_exact; p.counters = counters;
     p.flat_cnt = cnt; p.flat_cap = cap; p.flat_tau = tau; p.flat_lost = lost; p.flat_bad = bad;
-    p.dd_mult = fb.dd_mult; p.extra_rel = fb.extra_rel; p.extra_abs = fb.extra_abs; p.floor_out = nullptr;
+    p.dd_mult = fb.dd_mult; p.extra_rel = fb.extra_rel; p.extra_abs = fb.extra_abs; p.l2_bias = fb.l2_bias; p.floor_out = nullptr;
     const size_t lds = 1088 + (size_t)BAND_CAP * 20;
     hipError_t e = allow_lds(finalize_band_kernel, lds);
     if (e != hipSuccess) return e;

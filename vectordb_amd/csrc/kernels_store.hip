@@ -48,8 +48,9 @@ __device__ __forceinline__ float f16_to_f32(unsigned short b) {
 // canonical order without any data exchange besides the final tree.
 template <int DT>
 __global__ void __launch_bounds__(256)
-append_kernel(char* __restrict__ rows, long long* __restrict__ ids, float* __restrict__ n2out,
-              float* __restrict__ max_n2, long long row0, long long n, int d, int m, int metric,
+append_kernel(char* __restrict__ rows, unsigned short* __restrict__ rows16, long long ld16,
+              long long* __restrict__ ids, float* __restrict__ n2out,
+              float* __restrict__ max_n2, int* __restrict__ bad, long long row0, long long n, int d, int m, int metric,
               const float* __restrict__ raw, const long long* __restrict__ raw_ids,
               uint64_t seed, long long synth_first_row) {
     const int lane = threadIdx.x & 63;
@@ -73,6 +74,7 @@ append_kernel(char* __restrict__ rows, long long* __restrict__ ids, float* __res
         inv = (n2 == 0.0) ? 0.0 : 1.0 / sqrt(n2);
     }
     double acc2 = 0.0;
+    bool finite = true;
     for (int j = lane; j < dpad; j += 64) {
         float y = 0.f;
         if (j < d) {
@@ -82,6 +84,8 @@ append_kernel(char* __restrict__ rows, long long* __restrict__ ids, float* __res
         float stored;
         if constexpr (DT == VDB_F32) {
             ((float*)dst)[j] = y; stored = y;
+            // bf16 mirror for the batched fast pass (finite values only reach this point)
+            if (rows16) rows16[(size_t)(row0 + i) * ld16 + j] = f32_to_bf16_rne(y);
         } else if constexpr (DT == VDB_BF16) {
             const unsigned short b = f32_to_bf16_rne(y);
             ((unsigned short*)dst)[j] = b; stored = __uint_as_float((uint32_t)b << 16);
@@ -89,7 +93,14 @@ append_kernel(char* __restrict__ rows, long long* __restrict__ ids, float* __res
             const unsigned short b = f32_to_f16_rne(y);
             ((unsigned short*)dst)[j] = b; stored = f16_to_f32(b);
         }
+        finite = finite && (fabsf(stored) <= 3.0e38f);       // false for NaN, infinities and fp16 overflow
         acc2 = __dadd_rn(acc2, __dmul_rn((double)stored, (double)stored));
+    }
+    // a row that is not finite in the storage type makes the whole insert fail (the host does not
+    // publish the rows of this call) and stays out of the table-wide norm bound
+    finite = __all(finite);
+    if constexpr (DT == VDB_F32) {
+        if (rows16) for (int j = dpad + lane; j < ld16; j += 64) rows16[(size_t)(row0 + i) * ld16 + j] = 0;
     }
     const double sn2 = wave_tree_sum_d(acc2);
     if (lane == 0) {
@@ -97,13 +108,14 @@ append_kernel(char* __restrict__ rows, long long* __restrict__ ids, float* __res
         float f = (float)sn2;
         if ((double)f < sn2) f = __uint_as_float(__float_as_uint(f) + 1u);
         n2out[row0 + i] = (float)sn2;
-        atomicMax((unsigned int*)max_n2, __float_as_uint(f));
+        if (finite && f <= 3.0e38f) atomicMax((unsigned int*)max_n2, __float_as_uint(f));
+        else *bad = 1;
         ids[row0 + i] = synth ? (synth_first_row + i) : raw_ids[i];
     }
 }
 
-hipError_t launch_append(char* rows, long long* ids, float* n2, float* max_n2,
-                         long long row0, long long n, int d, int m, int dt, int metric,
+hipError_t launch_append(char* rows, unsigned short* rows16, long long ld16, long long* ids, float* n2, float* max_n2,
+                         int* bad, long long row0, long long n, int d, int m, int dt, int metric,
                          const float* raw, const long long* raw_ids,
                          uint64_t seed, long long synth_first_row, hipStream_t st) {
     // One wave per row: a launch holds at most 2^24 rows, because a grid of 2^32 work-items or more
@@ -115,12 +127,38 @@ hipError_t launch_append(char* rows, long long* ids, float* n2, float* max_n2,
         const float* raw_c = raw ? raw + (size_t)c0 * d : nullptr;
         const long long* ids_c = raw_ids ? raw_ids + c0 : nullptr;
 #define VDB_APPEND(DT)                                                                               \
-        hipLaunchKernelGGL((append_kernel<DT>), grid, block, 0, st, rows, ids, n2, max_n2, row0 + c0, nc, \
+        hipLaunchKernelGGL((append_kernel<DT>), grid, block, 0, st, rows, rows16, ld16, ids, n2, max_n2, bad, row0 + c0, nc, \
                            d, m, metric, raw_c, ids_c, seed, synth_first_row + c0)
         if (dt == VDB_F32) VDB_APPEND(VDB_F32);
         else if (dt == VDB_BF16) VDB_APPEND(VDB_BF16);
         else VDB_APPEND(VDB_F16);
 #undef VDB_APPEND
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+// bf16 mirror of stored fp32 rows (tables loaded from a snapshot): one wave per row
+__global__ void __launch_bounds__(256)
+build_mirror_kernel(const char* __restrict__ rows, unsigned short* __restrict__ rows16, long long ld16,
+                    long long row0, long long n, int m) {
+    const int lane = threadIdx.x & 63;
+    const long long i = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const float* src = (const float*)(rows + (size_t)(row0 + i) * ((size_t)m * 16));
+    unsigned short* dst = rows16 + (size_t)(row0 + i) * ld16;
+    const int dpad = m * 4;
+    for (int j = lane; j < ld16; j += 64) dst[j] = j < dpad ? f32_to_bf16_rne(src[j]) : (unsigned short)0;
+}
+
+hipError_t launch_build_mirror(const char* rows, unsigned short* rows16, long long ld16, long long row0,
+                               long long n, int m, hipStream_t st) {
+    const long long chunk = 1ll << 24;
+    for (long long c0 = 0; c0 < n; c0 += chunk) {
+        const long long nc = n - c0 < chunk ? n - c0 : chunk;
+        hipLaunchKernelGGL(build_mirror_kernel, dim3((unsigned)((nc + 3) / 4)), dim3(256), 0, st, rows, rows16, ld16,
+                           row0 + c0, nc, m);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }

@@ -46,9 +46,22 @@ struct Workspace {
     DevBuf small;                                         // batched path: cnt | lost | thr0 | thr1
     DevBuf cand_h;                                        // scan path: list heads
     DevBuf q16;                                           // batched path, 16-bit tables: query hi | lo parts
+    DevBuf qimg;                                          // batched path: tiled 16-bit image of the queries (ping-pong kernel)
     DevBuf q_raw, o_ids, o_scores, o_counts;              // staging of the host entry point (o_ids holds ids | scores | counts)
     void*  h_pin = nullptr;                               // pinned host mirror: queries | ids | scores | counts
     size_t h_cap = 0;
+};
+
+// A device array that grows in place: a virtual address range is reserved once for the largest size
+// the table can reach and backed by physical memory chunk by chunk (hipMemCreate / hipMemMap), so
+// that growth never copies or moves a row and never waits for searches in flight.  Where the
+// virtual-memory API is not available the array is a plain allocation that grows by allocate + copy.
+struct VArray {
+    char*  base = nullptr;
+    size_t reserved = 0;                 // bytes of address space (0 = plain allocation)
+    size_t mapped = 0;                   // bytes backed by memory
+    size_t chunk = 0;                    // every chunk of a range has this size
+    std::vector<std::pair<hipMemGenericAllocationHandle_t, size_t>> chunks;
 };
 
 struct Table {
@@ -57,15 +70,26 @@ struct Table {
     int metric = 0, dtype = 0;
     int m = 0;          // 16-byte units per row
     int dpad = 0;       // elements per padded row
-    int64_t rows = 0, cap = 0;
+    int64_t ld16 = 0;   // elements per row of the 16-bit image the batched pass multiplies (0 = none)
+    std::atomic<int64_t> rows{0};        // published row count: searches see rows [0, rows)
+    std::atomic<int64_t> cap{0};
+    VArray a_rows, a_ids, a_n2, a_rows16;
     char*      d_rows = nullptr;
     long long* d_ids = nullptr;
     float*     d_n2 = nullptr;
+    unsigned short* d_rows16 = nullptr;  // fp32 tables: bf16 mirror; 16-bit tables: alias of d_rows
     float*     d_maxn2 = nullptr;
-    std::shared_mutex mu;
+    int*       h_bad = nullptr;          // pinned, device-visible: set by an append that met a non-finite row
+    int*       d_bad = nullptr;          // device address of h_bad
+    bool       vmm = false;
+    std::shared_mutex mu;                // shared: searches and appends; exclusive: drop (and growth without VMM)
+    std::mutex ins_mu;                   // appends to this table run one at a time
     bool dropped = false;
 
-    size_t bytes_per_row() const { return (size_t)m * 16 + sizeof(long long) + sizeof(float); }
+    bool mirrored() const { return dtype == VDB_F32 && ld16 > 0; }
+    size_t bytes_per_row() const {
+        return (size_t)m * 16 + sizeof(long long) + sizeof(float) + (mirrored() ? (size_t)ld16 * 2 : 0);
+    }
 };
 
 struct HostReq;
@@ -82,6 +106,10 @@ struct Global {
     double cache_capacity_gb = 0.0;
     double insert_buffer_gb = 1.0;
     size_t table_bytes = 0;
+    int bf16_mirror = 1;                 // fp32 tables keep a bf16 image of their rows for the batched pass
+    int use_vmm = 1;                     // tables grow in reserved virtual ranges (0: allocate + copy)
+    size_t vmm_gran = 0;                 // allocation granularity of the virtual-memory API (0 = unavailable)
+    int tune_pp = 1;                     // batches over 128 queries run on the ping-pong kernel
     int tune_nt = 1, tune_waves = 8, tune_bpc = 4, tune_contig = 1, tune_gemm = 1, tune_split_f16 = 0, tune_split_bf16 = 0, tune_sample = 1, tune_gemm32s = 2;
     // host-insert staging (guarded by insert_mu)
     std::mutex insert_mu;
@@ -107,6 +135,8 @@ struct Global {
     int coalesce_host = 1;
 };
 static Global G;
+
+static size_t round_up(size_t v, size_t g) { return (v + g - 1) / g * g; }
 
 static int enter() {
     if (!G.inited) return fail(VDB_ESTATE, "vdb_init has not been called");
@@ -307,6 +337,7 @@ static int search_gemm_path(const TableView& tv, const SelGeom& g, int dpad, int
                             int k, long long* out_ids, float* out_scores, int* out_counts,
                             hipStream_t st, Workspace& ws) {
     const int K = g.K;
+    const bool l2 = tv.metric == VDB_METRIC_L2;
     const long long ntiles = (tv.n + 127) / 128;
     // Sample sizes of the threshold passes, in row tiles, smallest first.  Each pass is about
     // GEMM_TARGET / K times larger than the one before, so that the K-th best key of one pass,
@@ -346,7 +377,11 @@ static int search_gemm_path(const TableView& tv, const SelGeom& g, int dpad, int
     const bool s32 = !half && G.tune_gemm32s != 0;
     const int s32split = G.tune_gemm32s == 1 ? 1 : 0;
     const int qstride = (dpad + 63) / 64 * 64;       // 16-bit query rows: zero padded to whole k-steps of the kernels
+    // Batches of more than 128 queries run every pass but the first on the ping-pong kernel: 256 x 256
+    // tiles, operands straight from global memory into LDS; fp32 tables multiply their bf16 mirror.
+    const bool use_pp = G.tune_pp != 0 && nq > 128 && pp_eligible(tv, dpad) && ((half && !split) || (s32 && !s32split));
     FlatBound fb;
+    fb.l2_bias = use_pp ? 1.0 : 0.0;
     // accumulation chain in units of d: one per product, and a factor of two of margin on the
     // matrix unit's internal summation order and rounding
     fb.dd_mult = 2.0 * (s32 ? (s32split ? 3.0 : 1.0) : ((half && split) ? 2.0 : 1.0));
@@ -361,6 +396,7 @@ static int search_gemm_path(const TableView& tv, const SelGeom& g, int dpad, int
     if ((rc = ensure(ws.need_exact, (size_t)(nqc + 1) * sizeof(int), ws.last_stream))) return rc;
     if ((rc = ensure(ws.small, (size_t)nqc * 20, ws.last_stream))) return rc;
     if ((half || s32) && (rc = ensure(ws.q16, (size_t)nqc * qstride * 4, ws.last_stream))) return rc;
+    if (use_pp && (rc = ensure(ws.qimg, pp_query_image_bytes((int)nqc, dpad), ws.last_stream))) return rc;
     for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
         const int nqi = (int)(nq - q0 < chunk ? nq - q0 : chunk);
         float* qprep = (float*)ws.qprep.p;
@@ -383,6 +419,9 @@ static int search_gemm_path(const TableView& tv, const SelGeom& g, int dpad, int
         VDB_HIP(hipMemsetAsync(bad, 0, (size_t)nqc * 4, st));
         if (half) VDB_HIP(launch_split_query16(tv.dt, qprep, nqi, dpad, qstride, qhi, qlo, bad, st));
         if (s32) VDB_HIP(launch_split_query16(VDB_BF16, qprep, nqi, dpad, qstride, qhi, qlo, bad, st));
+        const bool pp = use_pp && nqi > 128;
+        const unsigned short* qimg = (const unsigned short*)ws.qimg.p;
+        if (pp) VDB_HIP(launch_tile_query16(half ? tv.dt : VDB_BF16, l2 ? 1 : 0, qprep, nqi, dpad, (unsigned short*)ws.qimg.p, bad, st));
         // pass 0: every score of the first n0 (<= GEMM_CAP) rows is kept, row r in slot r (no
         // counter traffic: a million atomics on nq addresses cost more than the whole pass);
         // thr0 = K-th best of them
@@ -397,7 +436,8 @@ static int search_gemm_path(const TableView& tv, const SelGeom& g, int dpad, int
             // strided sample of `tiles` row tiles under the current threshold -> next threshold
             const long long stride = ntiles / tiles;
             VDB_HIP(hipMemsetAsync(cnt, 0, (size_t)nqc * 8, st));
-            if (s32) VDB_HIP(launch_gemm32s(tv, qhi, qlo, qstride, s32split, nqi, dpad, tau, stride, cs, ct, cnt, lost, GEMM_CAP, G.n_cu, st));
+            if (pp) VDB_HIP(launch_gemm_pp(tv, qimg, nqi, dpad, tau, stride, cs, ct, cnt, lost, GEMM_CAP, G.n_cu, st));
+            else if (s32) VDB_HIP(launch_gemm32s(tv, qhi, qlo, qstride, s32split, nqi, dpad, tau, stride, cs, ct, cnt, lost, GEMM_CAP, G.n_cu, st));
             else VDB_HIP(gemm(tv, tau, stride, ntiles / stride, 0));
             VDB_HIP(launch_kth_threshold(cs, GEMM_CAP, cnt, 0, GEMM_CAP, K, tau, spare, nqi, st));
             std::swap(tau, spare);
@@ -406,7 +446,8 @@ static int search_gemm_path(const TableView& tv, const SelGeom& g, int dpad, int
         VDB_HIP(hipMemsetAsync(cnt, 0, (size_t)nqc * 8, st));
         ProfScope prof;
         if ((rc = prof.begin(st))) return rc;
-        if (s32) VDB_HIP(launch_gemm32s(tv, qhi, qlo, qstride, s32split, nqi, dpad, tau, 1, cs, ct, cnt, lost, GEMM_CAP, G.n_cu, st));
+        if (pp) VDB_HIP(launch_gemm_pp(tv, qimg, nqi, dpad, tau, 1, cs, ct, cnt, lost, GEMM_CAP, G.n_cu, st));
+        else if (s32) VDB_HIP(launch_gemm32s(tv, qhi, qlo, qstride, s32split, nqi, dpad, tau, 1, cs, ct, cnt, lost, GEMM_CAP, G.n_cu, st));
         else VDB_HIP(gemm(tv, tau, 1, ntiles, 0));
         if ((rc = prof.end(st))) return rc;
         VDB_HIP(launch_finalize_flat(tv, qprep, qinfo, nqi, dpad, g, k, cs, ct, cnt, GEMM_CAP, tau, lost, bad, fb,
@@ -423,7 +464,8 @@ static int search_core(Table& t, int64_t nq, const float* q_dev, int k, long lon
                        float* out_scores, int* out_counts, hipStream_t st, Workspace& ws) {
     TableView tv;
     tv.rows = t.d_rows; tv.ids = t.d_ids; tv.n2 = t.d_n2; tv.max_n2 = t.d_maxn2;
-    tv.n = t.rows; tv.d = (int)t.dim; tv.m = t.m; tv.dt = t.dtype; tv.metric = t.metric;
+    tv.rows16 = t.d_rows16; tv.ld16 = t.ld16;
+    tv.n = t.rows.load(std::memory_order_acquire); tv.d = (int)t.dim; tv.m = t.m; tv.dt = t.dtype; tv.metric = t.metric;
     const int l2 = t.metric == VDB_METRIC_L2;
     if (tv.n == 0) {
         const long long tot = nq * k > nq ? nq * k : nq;
@@ -460,64 +502,188 @@ static int search_core(Table& t, int64_t nq, const float* q_dev, int k, long lon
 }
 
 // ------------------------------------------------------------------------------ table storage
+
+static void varray_free(VArray& a) {
+    if (a.reserved) {
+        size_t off = 0;
+        for (auto& c : a.chunks) {
+            (void)hipMemUnmap(a.base + off, c.second);
+            (void)hipMemRelease(c.first);
+            off += c.second;
+        }
+        if (a.base) (void)hipMemAddressFree(a.base, a.reserved);
+    } else if (a.base) {
+        (void)hipFree(a.base);
+    }
+    a = VArray();
+}
+
+// Backs [mapped, want) of a reserved range, chunk by chunk.  All chunks of a range have one size:
+// chunks of mixed sizes were refused now and then on the MI355X box (hipMemSetAccess: invalid
+// argument, also for sizes and offsets that were multiples of 2 MiB and of each other), equal ones never.
+static hipError_t varray_map(VArray& a, size_t want) {
+    if (want > a.reserved) return hipErrorOutOfMemory;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = G.device;
+    hipMemAccessDesc acc = {};
+    acc.location.type = hipMemLocationTypeDevice;
+    acc.location.id = G.device;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    while (a.mapped < want) {
+        hipMemGenericAllocationHandle_t h;
+        hipError_t e = hipMemCreate(&h, a.chunk, &prop, 0);
+        if (e != hipSuccess) return e;
+        e = hipMemMap(a.base + a.mapped, a.chunk, 0, h, 0);
+        if (e != hipSuccess) { (void)hipMemRelease(h); return e; }
+        e = hipMemSetAccess(a.base + a.mapped, a.chunk, &acc, 1);
+        if (e != hipSuccess) { (void)hipMemUnmap(a.base + a.mapped, a.chunk); (void)hipMemRelease(h); return e; }
+        a.chunks.emplace_back(h, a.chunk);
+        a.mapped += a.chunk;
+    }
+    return hipSuccess;
+}
+
+// Largest row count a table is given address space for: what 320 GiB of rows hold (more than one
+// GPU's HBM), so that a table never runs out of range before it runs out of memory.
+static int64_t table_max_rows(const Table& t) {
+    const size_t per = (size_t)t.m * 16 > (size_t)t.ld16 * 2 ? (size_t)t.m * 16 : (size_t)t.ld16 * 2;
+    return (int64_t)(((size_t)320 << 30) / per);
+}
+
+static int table_reserve_ranges(Table& t) {
+    // called once, before the first row arrives; failure leaves the table on plain allocations
+    if (!G.use_vmm || G.vmm_gran == 0) return VDB_OK;
+    const int64_t mr = table_max_rows(t);
+    struct Want { VArray* a; size_t bytes; };
+    Want w[4] = {{&t.a_rows, (size_t)mr * t.m * 16}, {&t.a_ids, (size_t)mr * 8}, {&t.a_n2, (size_t)mr * 4},
+                 {&t.a_rows16, t.mirrored() ? (size_t)mr * t.ld16 * 2 : 0}};
+    for (auto& x : w) {
+        if (!x.bytes) continue;
+        void* p = nullptr;
+        // chunk: what 8192 rows take, as a power of two between 2 MiB and 1 GiB
+        size_t chunk = G.vmm_gran;
+        while (chunk < x.bytes / (size_t)mr * 8192 && chunk < ((size_t)1 << 30)) chunk <<= 1;
+        x.a->chunk = chunk;
+        const size_t sz = round_up(x.bytes + 256, chunk);
+        if (hipMemAddressReserve(&p, sz, 0, nullptr, 0) != hipSuccess || !p) {
+            (void)hipGetLastError();
+            for (auto& y : w) varray_free(*y.a);
+            return VDB_OK;                          // plain allocations instead
+        }
+        x.a->base = (char*)p;
+        x.a->reserved = sz;
+    }
+    t.vmm = true;
+    t.d_rows = t.a_rows.base; t.d_ids = (long long*)t.a_ids.base; t.d_n2 = (float*)t.a_n2.base;
+    t.d_rows16 = t.mirrored() ? (unsigned short*)t.a_rows16.base : (t.dtype != VDB_F32 ? (unsigned short*)t.d_rows : nullptr);
+    return VDB_OK;
+}
+
+static int budget_check(size_t extra) {
+    std::lock_guard<std::mutex> lk(G.mu);
+    if (G.cache_capacity_gb > 0.0 && (double)(G.table_bytes + extra) > G.cache_capacity_gb * 1073741824.0)
+        return fail(VDB_ENOMEM, "table storage would exceed gpu_resource_config.cache_capacity");
+    return VDB_OK;
+}
+
+// Capacity for at least new_cap rows.  With reserved ranges (the normal case) nothing moves and
+// searches in flight are not disturbed: the caller holds the table's shared lock and its append
+// mutex.  Without them the arrays are reallocated and copied: the caller holds the exclusive lock.
 static int table_alloc(Table& t, int64_t new_cap) {
-    // caller holds the table's exclusive lock
-    const size_t need = (size_t)new_cap * t.bytes_per_row();
-    const size_t have = (size_t)t.cap * t.bytes_per_row();
+    if (new_cap <= t.cap.load()) return VDB_OK;
+    if (new_cap > table_max_rows(t)) return fail(VDB_ENOMEM, "table would exceed the address range reserved for it");
+    if (t.vmm) {
+        struct Part { VArray* a; size_t per_row; };
+        Part parts[4] = {{&t.a_rows, (size_t)t.m * 16}, {&t.a_ids, 8}, {&t.a_n2, 4}, {&t.a_rows16, t.mirrored() ? (size_t)t.ld16 * 2 : 0}};
+        size_t want[4], extra = 0;
+        for (int i = 0; i < 4; ++i) {
+            want[i] = parts[i].per_row ? round_up((size_t)new_cap * parts[i].per_row + 256, parts[i].a->chunk) : 0;
+            if (want[i] > parts[i].a->reserved) want[i] = parts[i].a->reserved;
+            if (want[i] > parts[i].a->mapped) extra += want[i] - parts[i].a->mapped;
+        }
+        int rc = budget_check(extra);
+        if (rc) return rc;
+        for (int i = 0; i < 4; ++i) {
+            if (!parts[i].per_row) continue;
+            const size_t before = parts[i].a->mapped;
+            const hipError_t e = varray_map(*parts[i].a, want[i]);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                return fail(VDB_ENOMEM, std::string("mapping table memory: ") + hipGetErrorString(e));
+            }
+            std::lock_guard<std::mutex> lk(G.mu);
+            G.table_bytes += parts[i].a->mapped - before;
+        }
+        // rows that every mapped array holds
+        int64_t cap = INT64_MAX;
+        for (int i = 0; i < 4; ++i)
+            if (parts[i].per_row) { const int64_t c = (int64_t)((parts[i].a->mapped - 256) / parts[i].per_row); if (c < cap) cap = c; }
+        t.cap.store(cap);
+        return VDB_OK;
+    }
+    // plain allocations: new arrays, device-to-device copy of the rows present
+    const int64_t rows = t.rows.load();
+    const size_t sz[4] = {(size_t)new_cap * t.m * 16 + 256, (size_t)new_cap * 8, (size_t)new_cap * 4,
+                          t.mirrored() ? (size_t)new_cap * t.ld16 * 2 + 256 : 0};
+    size_t need = 0, have = 0;
+    VArray* arr[4] = {&t.a_rows, &t.a_ids, &t.a_n2, &t.a_rows16};
+    for (int i = 0; i < 4; ++i) { need += sz[i]; have += arr[i]->mapped; }
     {
         std::lock_guard<std::mutex> lk(G.mu);
-        if (G.cache_capacity_gb > 0.0) {
-            const double budget = G.cache_capacity_gb * 1073741824.0;
-            if ((double)(G.table_bytes - have + need) > budget)
-                return fail(VDB_ENOMEM, "table storage would exceed gpu_resource_config.cache_capacity");
-        }
+        if (G.cache_capacity_gb > 0.0 && (double)(G.table_bytes - have + need) > G.cache_capacity_gb * 1073741824.0)
+            return fail(VDB_ENOMEM, "table storage would exceed gpu_resource_config.cache_capacity");
     }
-    char* nr = nullptr; long long* ni = nullptr; float* nn = nullptr;
-    hipError_t e = hipMalloc((void**)&nr, (size_t)new_cap * t.m * 16);
-    if (e == hipSuccess) e = hipMalloc((void**)&ni, (size_t)new_cap * sizeof(long long));
-    if (e == hipSuccess) e = hipMalloc((void**)&nn, (size_t)new_cap * sizeof(float));
+    char* np[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 4 && e == hipSuccess; ++i) if (sz[i]) e = hipMalloc((void**)&np[i], sz[i]);
+    // searches enqueued earlier on caller streams may still read the old arrays
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    const size_t used[4] = {(size_t)rows * t.m * 16, (size_t)rows * 8, (size_t)rows * 4, (size_t)rows * t.ld16 * 2};
+    for (int i = 0; i < 4 && e == hipSuccess; ++i)
+        if (sz[i] && rows > 0) e = hipMemcpy(np[i], arr[i]->base, used[i], hipMemcpyDeviceToDevice);
     if (e != hipSuccess) {
-        if (nr) (void)hipFree(nr);
-        if (ni) (void)hipFree(ni);
-        if (nn) (void)hipFree(nn);
-        return fail(VDB_ENOMEM, std::string("hipMalloc for table rows: ") + hipGetErrorString(e));
+        (void)hipGetLastError();
+        for (int i = 0; i < 4; ++i) if (np[i]) (void)hipFree(np[i]);
+        return fail(VDB_ENOMEM, std::string("allocating table memory: ") + hipGetErrorString(e));
     }
-    // searches enqueued earlier on caller streams may still read the old buffers
-    VDB_HIP(hipDeviceSynchronize());
-    if (t.rows > 0) {
-        VDB_HIP(hipMemcpy(nr, t.d_rows, (size_t)t.rows * t.m * 16, hipMemcpyDeviceToDevice));
-        VDB_HIP(hipMemcpy(ni, t.d_ids, (size_t)t.rows * sizeof(long long), hipMemcpyDeviceToDevice));
-        VDB_HIP(hipMemcpy(nn, t.d_n2, (size_t)t.rows * sizeof(float), hipMemcpyDeviceToDevice));
+    for (int i = 0; i < 4; ++i) {
+        if (arr[i]->base) (void)hipFree(arr[i]->base);
+        arr[i]->base = np[i]; arr[i]->mapped = sz[i]; arr[i]->reserved = 0;
     }
-    if (t.d_rows) (void)hipFree(t.d_rows);
-    if (t.d_ids) (void)hipFree(t.d_ids);
-    if (t.d_n2) (void)hipFree(t.d_n2);
-    t.d_rows = nr; t.d_ids = ni; t.d_n2 = nn;
+    t.d_rows = t.a_rows.base; t.d_ids = (long long*)t.a_ids.base; t.d_n2 = (float*)t.a_n2.base;
+    t.d_rows16 = t.mirrored() ? (unsigned short*)t.a_rows16.base : (t.dtype != VDB_F32 ? (unsigned short*)t.d_rows : nullptr);
     {
         std::lock_guard<std::mutex> lk(G.mu);
         G.table_bytes = G.table_bytes - have + need;
     }
-    t.cap = new_cap;
+    t.cap.store(new_cap);
     return VDB_OK;
 }
 
 static int table_grow_for(Table& t, int64_t extra) {
-    if (t.rows + extra <= t.cap) return VDB_OK;
-    int64_t nc = t.cap * 2;
-    if (nc < t.rows + extra) nc = t.rows + extra;
+    const int64_t rows = t.rows.load(), cap = t.cap.load();
+    if (rows + extra <= cap) return VDB_OK;
+    int64_t nc = cap + (cap < ((int64_t)1 << 22) ? cap : cap / 4);      // doubles while small, then grows by a quarter
+    if (nc < rows + extra) nc = rows + extra;
     if (nc < 1024) nc = 1024;
-    return table_alloc(t, nc);
+    const int64_t mr = table_max_rows(t);
+    if (nc > mr) nc = mr;
+    int rc = table_alloc(t, nc);
+    if (rc == VDB_ENOMEM && nc > rows + extra) rc = table_alloc(t, rows + extra);    // exactly what is needed
+    return rc;
 }
 
 static void table_free(Table& t) {
     (void)hipDeviceSynchronize();
-    const size_t have = (size_t)t.cap * t.bytes_per_row();
-    if (t.d_rows) (void)hipFree(t.d_rows);
-    if (t.d_ids) (void)hipFree(t.d_ids);
-    if (t.d_n2) (void)hipFree(t.d_n2);
+    size_t have = 0;
+    for (VArray* a : {&t.a_rows, &t.a_ids, &t.a_n2, &t.a_rows16}) { have += a->mapped; varray_free(*a); }
     if (t.d_maxn2) (void)hipFree(t.d_maxn2);
-    t.d_rows = nullptr; t.d_ids = nullptr; t.d_n2 = nullptr; t.d_maxn2 = nullptr;
-    t.rows = 0; t.cap = 0; t.dropped = true;
+    if (t.h_bad) (void)hipHostFree(t.h_bad);
+    t.d_rows = nullptr; t.d_ids = nullptr; t.d_n2 = nullptr; t.d_rows16 = nullptr; t.d_maxn2 = nullptr;
+    t.h_bad = nullptr; t.d_bad = nullptr;
+    t.rows.store(0); t.cap.store(0); t.dropped = true;
     std::lock_guard<std::mutex> lk(G.mu);
     G.table_bytes -= have;
 }
@@ -554,6 +720,22 @@ int vdb_init(int device) {
     if (e == hipSuccess) e = hipStreamCreate(&G.insert_stream);
     if (e != hipSuccess) return fail(VDB_ENOGPU, std::string("device set-up: ") + hipGetErrorString(e));
     G.device = device;
+    {
+        // allocation granularity of the virtual-memory API; 0 leaves tables on plain allocations
+        hipMemAllocationProp prop = {};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = device;
+        size_t gran = 0;
+        // chunks are sized and placed in multiples of 2 MiB whatever smaller granule the runtime reports:
+        // access rights on a chunk at a 4 KiB granule offset were refused (hipMemSetAccess: invalid argument)
+        size_t own = (size_t)2 << 20;
+        if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) == hipSuccess && gran > 0) {
+            while (own < gran) own <<= 1;
+            G.vmm_gran = own;
+        }
+        else { (void)hipGetLastError(); G.vmm_gran = 0; }
+    }
     G.inited = true;
     return VDB_OK;
 }
@@ -575,7 +757,7 @@ int vdb_shutdown(void) {
     std::lock_guard<std::mutex> lk(G.mu);
     for (auto& w : G.free_ws) {
         for (DevBuf* b : {&w->qprep, &w->qinfo, &w->cand_s, &w->cand_t, &w->need_exact, &w->q_raw,
-                          &w->o_ids, &w->o_scores, &w->o_counts, &w->small, &w->cand_h, &w->q16})
+                          &w->o_ids, &w->o_scores, &w->o_counts, &w->small, &w->cand_h, &w->q16, &w->qimg})
             if (b->p) (void)hipFree(b->p);
         if (w->h_pin) (void)hipHostFree(w->h_pin);
         if (w->stream) (void)hipStreamDestroy(w->stream);
@@ -623,6 +805,9 @@ int vdb_set_option(const char* key, double value) {
     else if (k == "gemm32_split") G.tune_gemm32s = value < 0 ? 0 : value > 2 ? 2 : (int)value;
     else if (k == "gemm_split_bf16") G.tune_split_bf16 = value != 0;
     else if (k == "gemm32s_threads") set_gemm32s_threads((int)value);
+    else if (k == "gemm_pp") G.tune_pp = value != 0;
+    else if (k == "bf16_mirror") G.bf16_mirror = value != 0;
+    else if (k == "virtual_ranges") G.use_vmm = value != 0;
     else return fail(VDB_EINVAL, "unknown option: " + k);
     set_scan_tune(G.tune_nt, G.tune_waves, G.tune_bpc, G.tune_contig);
     return VDB_OK;
@@ -641,11 +826,23 @@ int vdb_create_table(const char* name, int64_t dim, int metric, int dtype) {
     const int epl = elems_per_unit(dtype);
     t->m = (int)((dim + epl - 1) / epl);
     t->dpad = t->m * epl;
-    VDB_HIP(hipMalloc((void**)&t->d_maxn2, sizeof(float)));
-    VDB_HIP(hipMemset(t->d_maxn2, 0, sizeof(float)));
+    if (dtype == VDB_F32) t->ld16 = G.bf16_mirror ? (dim + 31) / 32 * 32 : 0;
+    else t->ld16 = (int64_t)t->m * 8;
+    VDB_HIP(hipMalloc((void**)&t->d_maxn2, 16));
+    VDB_HIP(hipMemset(t->d_maxn2, 0, 16));
+    hipError_t e = hipHostMalloc((void**)&t->h_bad, sizeof(int), hipHostMallocMapped);
+    if (e == hipSuccess) { *t->h_bad = 0; e = hipHostGetDevicePointer((void**)&t->d_bad, t->h_bad, 0); }
+    if (e != hipSuccess) {
+        (void)hipFree(t->d_maxn2);
+        if (t->h_bad) (void)hipHostFree(t->h_bad);
+        return fail(VDB_EHIP, std::string("pinned flag for appends: ") + hipGetErrorString(e));
+    }
+    (void)table_reserve_ranges(*t);
     std::lock_guard<std::mutex> lk(G.mu);
     if (G.tables.count(name)) {
+        for (VArray* a : {&t->a_rows, &t->a_ids, &t->a_n2, &t->a_rows16}) varray_free(*a);
         (void)hipFree(t->d_maxn2);
+        (void)hipHostFree(t->h_bad);
         return fail(VDB_EEXISTS, std::string("table exists: ") + name);
     }
     G.tables[name] = t;
@@ -691,7 +888,7 @@ int vdb_count(const char* name, int64_t* out_rows) {
     auto t = find_table(name);
     if (!t) return fail(VDB_ENOTFOUND, std::string("no such table: ") + name);
     std::shared_lock<std::shared_mutex> tl(t->mu);
-    *out_rows = t->rows;
+    *out_rows = t->rows.load();
     return VDB_OK;
 }
 
@@ -705,8 +902,8 @@ int vdb_table_info(const char* name, int64_t* dim, int* metric, int* dtype, int6
     if (dim) *dim = t->dim;
     if (metric) *metric = t->metric;
     if (dtype) *dtype = t->dtype;
-    if (rows) *rows = t->rows;
-    if (capacity) *capacity = t->cap;
+    if (rows) *rows = t->rows.load();
+    if (capacity) *capacity = t->cap.load();
     if (row_stride_bytes) *row_stride_bytes = (int64_t)t->m * 16;
     return VDB_OK;
 }
@@ -717,10 +914,58 @@ int vdb_reserve(const char* name, int64_t rows) {
     if (!name || rows < 0) return fail(VDB_EINVAL, "bad argument");
     auto t = find_table(name);
     if (!t) return fail(VDB_ENOTFOUND, std::string("no such table: ") + name);
+    if (t->vmm) {
+        std::shared_lock<std::shared_mutex> tl(t->mu);
+        std::lock_guard<std::mutex> il(t->ins_mu);
+        if (t->dropped) return fail(VDB_ENOTFOUND, "table was dropped");
+        return table_alloc(*t, rows);
+    }
     std::unique_lock<std::shared_mutex> tl(t->mu);
+    std::lock_guard<std::mutex> il(t->ins_mu);
     if (t->dropped) return fail(VDB_ENOTFOUND, "table was dropped");
-    if (rows <= t->cap) return VDB_OK;
     return table_alloc(*t, rows);
+}
+
+// Appends run one at a time per table and beside searches: the new rows are written behind the
+// published row count, the stream is drained, and only then is the count advanced (one atomic
+// store), so a search sees either none or all rows of a call.  A call that meets a row that is not
+// finite in the table's storage type publishes nothing and fails with VDB_EINVAL.
+static int insert_locked(Table& t, int64_t n, const float* rows, const long long* ids,
+                         bool host, bool synth, uint64_t seed, int64_t first_row, hipStream_t user_st) {
+    int rc;
+    if ((rc = table_grow_for(t, n))) return rc;
+    const int d = (int)t.dim;
+    const int64_t base = t.rows.load();
+    unsigned short* mirror = t.mirrored() ? t.d_rows16 : nullptr;
+    *t.h_bad = 0;
+    if (synth || !host) {
+        hipStream_t st = synth ? G.insert_stream : user_st;
+        VDB_HIP(launch_append(t.d_rows, mirror, t.ld16, t.d_ids, t.d_n2, t.d_maxn2, t.d_bad, base, n, d, t.m, t.dtype,
+                              t.metric, synth ? nullptr : rows, synth ? nullptr : ids, seed, first_row, st));
+        VDB_HIP(hipStreamSynchronize(st));
+    } else {
+        std::lock_guard<std::mutex> il(G.insert_mu);
+        double cap_rows_d = G.insert_buffer_gb * 1073741824.0 / ((double)d * sizeof(float) + sizeof(long long));
+        int64_t chunk = cap_rows_d > 1e15 ? n : (int64_t)cap_rows_d;
+        if (chunk < 1) chunk = 1;
+        if (chunk > n) chunk = n;
+        if ((rc = ensure(G.stage_rows, (size_t)chunk * d * sizeof(float), G.insert_stream))) return rc;
+        if ((rc = ensure(G.stage_ids, (size_t)chunk * sizeof(long long), G.insert_stream))) return rc;
+        for (int64_t i0 = 0; i0 < n; i0 += chunk) {
+            const int64_t ni = n - i0 < chunk ? n - i0 : chunk;
+            VDB_HIP(hipMemcpyAsync(G.stage_rows.p, rows + (size_t)i0 * d, (size_t)ni * d * sizeof(float),
+                                   hipMemcpyHostToDevice, G.insert_stream));
+            VDB_HIP(hipMemcpyAsync(G.stage_ids.p, ids + i0, (size_t)ni * sizeof(long long),
+                                   hipMemcpyHostToDevice, G.insert_stream));
+            VDB_HIP(launch_append(t.d_rows, mirror, t.ld16, t.d_ids, t.d_n2, t.d_maxn2, t.d_bad, base + i0, ni, d, t.m,
+                                  t.dtype, t.metric, (const float*)G.stage_rows.p, (const long long*)G.stage_ids.p,
+                                  0, 0, G.insert_stream));
+            VDB_HIP(hipStreamSynchronize(G.insert_stream));      // the staging buffers are reused by the next chunk
+        }
+    }
+    if (*t.h_bad) return fail(VDB_EINVAL, "a row holds a value that is not finite in the table's storage type; nothing was inserted");
+    t.rows.store(base + n, std::memory_order_release);
+    return VDB_OK;
 }
 
 static int insert_common(const char* name, int64_t n, const float* rows, const long long* ids,
@@ -732,45 +977,17 @@ static int insert_common(const char* name, int64_t n, const float* rows, const l
     auto t = find_table(name);
     if (!t) return fail(VDB_ENOTFOUND, std::string("no such table: ") + name);
     if (n == 0) return VDB_OK;
+    if (t->vmm) {
+        // searches keep running: nothing they read moves or changes
+        std::shared_lock<std::shared_mutex> tl(t->mu);
+        std::lock_guard<std::mutex> il(t->ins_mu);
+        if (t->dropped) return fail(VDB_ENOTFOUND, "table was dropped");
+        return insert_locked(*t, n, rows, ids, host, synth, seed, first_row, user_st);
+    }
     std::unique_lock<std::shared_mutex> tl(t->mu);
+    std::lock_guard<std::mutex> il(t->ins_mu);
     if (t->dropped) return fail(VDB_ENOTFOUND, "table was dropped");
-    if ((rc = table_grow_for(*t, n))) return rc;
-    const int d = (int)t->dim;
-    if (synth) {
-        VDB_HIP(launch_append(t->d_rows, t->d_ids, t->d_n2, t->d_maxn2, t->rows, n, d, t->m, t->dtype,
-                              t->metric, nullptr, nullptr, seed, first_row, G.insert_stream));
-        VDB_HIP(hipStreamSynchronize(G.insert_stream));
-        t->rows += n;
-        return VDB_OK;
-    }
-    if (!host) {
-        hipStream_t st = user_st;
-        VDB_HIP(launch_append(t->d_rows, t->d_ids, t->d_n2, t->d_maxn2, t->rows, n, d, t->m, t->dtype,
-                              t->metric, rows, ids, 0, 0, st));
-        VDB_HIP(hipStreamSynchronize(st));   // rows become visible to searches on any stream
-        t->rows += n;
-        return VDB_OK;
-    }
-    std::lock_guard<std::mutex> il(G.insert_mu);
-    double cap_rows_d = G.insert_buffer_gb * 1073741824.0 / ((double)d * sizeof(float) + sizeof(long long));
-    int64_t chunk = cap_rows_d > 1e15 ? n : (int64_t)cap_rows_d;
-    if (chunk < 1) chunk = 1;
-    if (chunk > n) chunk = n;
-    if ((rc = ensure(G.stage_rows, (size_t)chunk * d * sizeof(float), G.insert_stream))) return rc;
-    if ((rc = ensure(G.stage_ids, (size_t)chunk * sizeof(long long), G.insert_stream))) return rc;
-    for (int64_t i0 = 0; i0 < n; i0 += chunk) {
-        const int64_t ni = n - i0 < chunk ? n - i0 : chunk;
-        VDB_HIP(hipMemcpyAsync(G.stage_rows.p, rows + (size_t)i0 * d, (size_t)ni * d * sizeof(float),
-                               hipMemcpyHostToDevice, G.insert_stream));
-        VDB_HIP(hipMemcpyAsync(G.stage_ids.p, ids + i0, (size_t)ni * sizeof(long long),
-                               hipMemcpyHostToDevice, G.insert_stream));
-        VDB_HIP(launch_append(t->d_rows, t->d_ids, t->d_n2, t->d_maxn2, t->rows, ni, d, t->m, t->dtype,
-                              t->metric, (const float*)G.stage_rows.p, (const long long*)G.stage_ids.p,
-                              0, 0, G.insert_stream));
-        VDB_HIP(hipStreamSynchronize(G.insert_stream));
-        t->rows += ni;
-    }
-    return VDB_OK;
+    return insert_locked(*t, n, rows, ids, host, synth, seed, first_row, user_st);
 }
 
 int vdb_insert(const char* name, int64_t n, const float* rows, const int64_t* ids) {
@@ -800,7 +1017,7 @@ int vdb_fetch_rows(const char* name, int64_t first, int64_t n, float* out_rows, 
     auto t = find_table(name);
     if (!t) return fail(VDB_ENOTFOUND, std::string("no such table: ") + name);
     std::shared_lock<std::shared_mutex> tl(t->mu);
-    if (first + n > t->rows) return fail(VDB_EINVAL, "row range beyond the table");
+    if (first + n > t->rows.load()) return fail(VDB_EINVAL, "row range beyond the table");
     if (n == 0) return VDB_OK;
     if (out_rows) {
         float* tmp = nullptr;
@@ -867,7 +1084,7 @@ int vdb_save_table(const char* name, const char* path) {
     SnapHeader h;
     std::memset(&h, 0, sizeof h);
     std::memcpy(h.magic, "VDBSNAP1", 8);
-    h.dim = t->dim; h.metric = t->metric; h.dtype = t->dtype; h.rows = t->rows; h.m = t->m;
+    h.dim = t->dim; h.metric = t->metric; h.dtype = t->dtype; h.rows = t->rows.load(); h.m = t->m;
     VDB_HIP(hipMemcpy(&h.max_n2, t->d_maxn2, sizeof(float), hipMemcpyDeviceToHost));
     HostPinned hp;
     VDB_HIP(hipHostMalloc(&hp.p, SNAP_CHUNK, hipHostMallocDefault));
@@ -877,10 +1094,10 @@ int vdb_save_table(const char* name, const char* path) {
         fc.f = fopen(tmp.c_str(), "wb");
         if (!fc.f) return fail(VDB_EINVAL, "cannot open snapshot file for writing: " + tmp);
         if (fwrite(&h, sizeof h, 1, fc.f) != 1) return fail(VDB_EINVAL, "short write to snapshot file");
-        if (t->rows > 0) {
-            if ((rc = snap_write(fc.f, t->d_rows, (size_t)t->rows * t->m * 16, hp.p))) return rc;
-            if ((rc = snap_write(fc.f, (const char*)t->d_ids, (size_t)t->rows * sizeof(long long), hp.p))) return rc;
-            if ((rc = snap_write(fc.f, (const char*)t->d_n2, (size_t)t->rows * sizeof(float), hp.p))) return rc;
+        if (h.rows > 0) {
+            if ((rc = snap_write(fc.f, t->d_rows, (size_t)h.rows * t->m * 16, hp.p))) return rc;
+            if ((rc = snap_write(fc.f, (const char*)t->d_ids, (size_t)h.rows * sizeof(long long), hp.p))) return rc;
+            if ((rc = snap_write(fc.f, (const char*)t->d_n2, (size_t)h.rows * sizeof(float), hp.p))) return rc;
         }
         if (fflush(fc.f) != 0) return fail(VDB_EINVAL, "flush of snapshot file failed");
     }
@@ -918,6 +1135,7 @@ int vdb_load_table(const char* name, const char* path) {
     if (!t) return fail(VDB_ESTATE, "table vanished while loading");
     {
         std::unique_lock<std::shared_mutex> tl(t->mu);
+        std::lock_guard<std::mutex> il(t->ins_mu);
         if (h.rows > 0) {
             HostPinned hp;
             rc = table_alloc(*t, h.rows);
@@ -926,10 +1144,16 @@ int vdb_load_table(const char* name, const char* path) {
             if (!rc) rc = snap_read(fc.f, t->d_rows, (size_t)h.rows * h.m * 16, hp.p);
             if (!rc) rc = snap_read(fc.f, (char*)t->d_ids, (size_t)h.rows * sizeof(long long), hp.p);
             if (!rc) rc = snap_read(fc.f, (char*)t->d_n2, (size_t)h.rows * sizeof(float), hp.p);
+            if (!rc && t->mirrored()) {
+                // the bf16 image of the rows is derived data: rebuilt, not stored
+                hipError_t e = launch_build_mirror(t->d_rows, t->d_rows16, t->ld16, 0, h.rows, t->m, nullptr);
+                if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+                if (e != hipSuccess) rc = fail(VDB_EHIP, std::string("rebuilding the bf16 image: ") + hipGetErrorString(e));
+            }
         }
         if (!rc && hipMemcpy(t->d_maxn2, &h.max_n2, sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
             rc = fail(VDB_EHIP, "cannot store the row-norm bound");
-        if (!rc) t->rows = h.rows;
+        if (!rc) t->rows.store(h.rows);
     }
     if (rc) {
         const std::string keep = tl_error;

@@ -19,6 +19,9 @@ struct TableView {
     const long long* ids;       // [n]
     const float*     n2;        // [n] fp32 squared norm of the stored row
     const float*     max_n2;    // device scalar: max over rows of n2
+    const unsigned short* rows16; // fp32 tables: bf16 mirror [n][ld16] of the stored rows (may be null);
+                                //            16-bit tables: the rows themselves
+    long long        ld16;      // elements per row of rows16 (fp32 tables: a multiple of 32, zero padded)
     long long        n;
     int              d;         // logical dimension
     int              m;         // 16-byte units per row
@@ -74,6 +77,7 @@ hipError_t launch_finalize(const TableView& t, const float* qprep, const QInfo* 
 // appended, every non-candidate row known to have a fast key <= tau[q].
 // Terms the batched path adds to the fp32 scoring-error bound of the certificate.
 struct FlatBound {
+    double l2_bias = 0.0;     // 1 when L2 keys are accumulated on top of the row norm (partial sums of that size)
     double dd_mult = 1.0;     // accumulation chain length in units of d (2 when hi and lo parts are summed)
     double extra_rel = 0.0;   // relative error of the query as the MFMA sees it (x ||x|| ||q||)
     double extra_abs = 0.0;   // absolute error per unit of ||x|| (fp16 subnormal spacing)
@@ -99,6 +103,16 @@ hipError_t launch_gemm16_thresh(const TableView& t, const unsigned short* qhi, c
                                 float* cand_s, long long* cand_t, int* cnt, int* lost, int cap, int dense,
                                 int n_cu, hipStream_t st);
 void set_gemm32s_threads(int v);
+// Ping-pong kernel (gemm_pp.h): 256 x 256 tiles over t.rows16 with the queries as a tiled 16-bit image
+// (launch_tile_query16); visits every tile_stride-th 256-row tile.  Needs nks * 32 <= t.ld16 or, for
+// 16-bit tables, dpad a multiple of 32 (pp_eligible).
+bool pp_eligible(const TableView& t, int dpad);
+size_t pp_query_image_bytes(int nq, int dpad);
+hipError_t launch_tile_query16(int dt, int l2, const float* qprep, int nq, int dpad, unsigned short* image,
+                               int* bad, hipStream_t st);
+hipError_t launch_gemm_pp(const TableView& t, const unsigned short* qimage, int nq, int dpad, const float* thr,
+                          long long tile_stride, float* cand_s, long long* cand_t, int* cnt, int* lost, int cap,
+                          int n_cu, hipStream_t st);
 hipError_t launch_gemm32s(const TableView& t, const unsigned short* qhi, const unsigned short* qlo, int qstride,
                           int split, int nq, int dpad, const float* thr, long long tile_stride,
                           float* cand_s, long long* cand_t,
@@ -117,10 +131,15 @@ hipError_t launch_exact(const TableView& t, const float* qprep, int64_t nq, int 
                         int* need_exact, long long* counters, hipStream_t st);
 
 // Append n rows (raw fp32 from `raw`, or synthetic when raw == nullptr) at row index `row0`.
-hipError_t launch_append(char* rows, long long* ids, float* n2, float* max_n2,
-                         long long row0, long long n, int d, int m, int dt, int metric,
+// *bad (host-visible) is set when a row is not finite in the storage type
+hipError_t launch_append(char* rows, unsigned short* rows16, long long ld16, long long* ids, float* n2, float* max_n2,
+                         int* bad, long long row0, long long n, int d, int m, int dt, int metric,
                          const float* raw, const long long* raw_ids,
                          uint64_t seed, long long synth_first_row, hipStream_t st);
+
+// (re)builds the bf16 mirror of rows [row0, row0 + n) of an fp32 table from the stored rows
+hipError_t launch_build_mirror(const char* rows, unsigned short* rows16, long long ld16, long long row0,
+                               long long n, int m, hipStream_t st);
 
 hipError_t launch_synth_fill(float* out, long long n, int d, uint64_t seed, long long first_row,
                              hipStream_t st);
