@@ -2,45 +2,44 @@
 """Headline benchmark: QPS of single-query cosine top-10 over 10M x 768 fp32 rows held in HBM.
 
   python bench.py --gpus 1 --steps 100 --warmup 10
+  python bench.py --gpus N ...                      (starts its own N ranks, one per GPU)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step = one query scored against every stored row, exact top-10 returned (ids + scores) in
-device memory.  With N > 1 the 10M rows are row-sharded over the N ranks (strong scaling): each
-rank scans its shard, one RCCL all-gather exchanges the per-rank top-10 records, every rank
-merges them.  Inputs (table and queries) are resident in HBM before the timed region.
-Single-query steps are issued round-robin on --streams HIP streams (default 3), as the requests
-of concurrent clients are: the library runs the table scans strictly one after the other, and the
-short kernels and the collective around one scan overlap with the next query's scan.
+A step = one query (or one batch of --nq queries) scored against every stored row, exact top-k
+returned (ids + scores) in device memory.  With N > 1 the rows are row-sharded over the N ranks
+(strong scaling): each rank scans its shard, one RCCL all-gather exchanges the per-rank top-k
+records, every rank merges them.  Inputs (table and queries) are resident in HBM before the timed
+region.  Single-query steps are issued round-robin on --streams HIP streams (default 3), as the
+requests of concurrent clients are: the library runs the table scans strictly one after the other,
+and the short kernels and the collective around one scan overlap with the next query's scan.
 
-Prints ONE JSON line (rank 0) with the throughput, the roofline of the dominant kernel (the scan:
-algorithmic bytes = rows_per_gpu * dim * 4 per launch over its HIP-event duration inside the
-timed region, against 8 TB/s HBM), and a CPU baseline (the numpy/BLAS port of the same search,
-timed on this host on a bounded sample of the same workload and scaled by rows).
+Prints ONE JSON line (rank 0): the throughput, the roofline of the dominant kernel (single queries:
+the scan, algorithmic bytes = rows_per_gpu * dim * element size per launch over its HIP-event
+duration inside the timed region, against 8 TB/s of HBM; batches: the full pass of the MFMA kernel,
+2 * rows * dim * queries flops per launch against the dense 16-bit MFMA peak), a CPU baseline (the
+numpy/BLAS port of the same search, timed on this host on a bounded sample of the same workload and
+scaled by rows), and, on one GPU with the default workload, a `secondary` list: the other BASELINE
+configurations that fit one GPU, measured in the same run, each with its own roofline.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 import numpy as np
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from vectordb_amd import _lib                      # noqa: E402
-from vectordb_amd.engine import Engine             # noqa: E402
-from vectordb_amd.sharded import ShardedSearcher, gpu_backend, shard_range  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0
 MFMA_F32_PEAK_TF = 157.3          # dense fp32-input MFMA peak of one MI355X
-DTYPES = {"f32": (_lib.F32, 4), "bf16": (_lib.BF16, 2), "f16": (_lib.F16, 2)}
-METRICS = {"cosine": _lib.METRIC_COSINE, "ip": _lib.METRIC_IP, "l2": _lib.METRIC_L2}
+MFMA_16_PEAK_TF = 2500.0          # dense bf16 / fp16 MFMA peak
 
 
 def cpu_baseline(rows_total: int, dim: int, k: int, metric_name: str, budget_s: float):
@@ -81,6 +80,33 @@ def cpu_baseline(rows_total: int, dim: int, k: int, metric_name: str, budget_s: 
     }
 
 
+def spawn_ranks(n: int, argv) -> int:
+    """`bench.py --gpus N` from a bare shell: this process touches no GPU; it starts N fresh rank
+    processes (one per GPU, rendezvous on 127.0.0.1), relays rank 0's JSON line and returns non-zero
+    if any rank failed."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        p.wait()
+        rc = rc or p.returncode
+    # rank 0's JSON line only (the gloo backend prints a connection notice on stdout)
+    for ln in (out or "").splitlines():
+        (sys.stdout if ln.startswith("{") else sys.stderr).write(ln + "\n")
+    sys.stdout.flush()
+    return rc
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -90,8 +116,8 @@ def main() -> None:
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--nq", type=int, default=1, help="queries per step")
-    ap.add_argument("--metric", default="cosine", choices=sorted(METRICS))
-    ap.add_argument("--dtype", default="f32", choices=sorted(DTYPES))
+    ap.add_argument("--metric", default="cosine", choices=["cosine", "ip", "l2"])
+    ap.add_argument("--dtype", default="f32", choices=["bf16", "f16", "f32"])
     ap.add_argument("--streams", type=int, default=3,
                     help="queries in flight: step i runs on HIP stream i %% streams, as the requests of "
                          "concurrent clients do; the library runs the table scans one after the other and "
@@ -101,19 +127,38 @@ def main() -> None:
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="0 disables the CPU baseline")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (nccl = RCCL; gloo rehearses the path on fewer GPUs)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the other BASELINE configurations measured after the headline on one GPU")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))      # before anything touches a GPU
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    rank_main(args, world)
+
+
+def rank_main(args, world: int) -> None:
+    import torch
+    import torch.distributed as dist
+
+    from vectordb_amd import _lib
+    from vectordb_amd.engine import Engine
+    from vectordb_amd.sharded import ShardedSearcher, gpu_backend, shard_range
+
+    DTYPES = {"f32": (_lib.F32, 4), "bf16": (_lib.BF16, 2), "f16": (_lib.F16, 2)}
+    METRICS = {"cosine": _lib.METRIC_COSINE, "ip": _lib.METRIC_IP, "l2": _lib.METRIC_L2}
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU path exists)")
     ndev = torch.cuda.device_count()
     dev_index = local_rank % ndev          # ranks share a GPU only in the --backend gloo rehearsal
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    ranks_seen = 1
     if world > 1:
         if args.backend == "nccl":
             if world > ndev:
@@ -121,12 +166,175 @@ def main() -> None:
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
+        # how many ranks the collective backend really joins: a sum of ones over the group
+        ones = torch.ones(1, dtype=torch.int32, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
 
     eng = Engine(device=dev_index)
     for kv in args.opt:
         key, _, val = kv.partition("=")
         eng.set_option(key, float(val))
-    dt, esz = DTYPES[args.dtype]
+    opts = dict(o.split("=", 1) for o in args.opt)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def run_workload(table, rows_total, n_local, dim, dtype, metric_name, k, nq, steps, warmup, n_streams, latency):
+        """Times `steps` steps on an existing table; returns the measured entry (rank 0's view)."""
+        esz = DTYPES[dtype][1]
+        metric = METRICS[metric_name]
+        total = steps + warmup
+        queries = torch.empty((total * nq, dim), dtype=torch.float32, device=dev)
+        stream = torch.cuda.current_stream()
+        eng.synth_fill_dev(queries.data_ptr(), total * nq, dim, seed=1, first_row=0, stream=stream.cuda_stream)
+        local_search, merge = gpu_backend(eng, table, nq, k, metric)
+        # batches keep the GPU busy on their own; single queries are pipelined over several streams
+        n_streams = max(1, n_streams) if nq == 1 else 1
+        searchers = [ShardedSearcher(nq, k, dev, local_search, merge) for _ in range(n_streams)]
+        streams = [stream] if n_streams == 1 else [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
+        torch.cuda.synchronize()
+
+        def step(i: int):
+            slot = i % n_streams
+            with torch.cuda.stream(streams[slot]):
+                return searchers[slot].search(queries[i * nq:(i + 1) * nq])
+
+        q0, f0, b0 = eng.stats()
+        for i in range(warmup):
+            step(i)
+        fence()
+        eng.prof_read()
+        eng.prof_enable(True)
+        t0 = time.perf_counter()
+        out = None
+        for i in range(warmup, total):
+            out = step(i)
+        fence()
+        elapsed = time.perf_counter() - t0
+        eng.prof_enable(False)
+        kern_ms, launches = eng.prof_read()
+        last_ids = out.ids.cpu().numpy().copy()
+        last_scores = out.scores.cpu().numpy().copy()
+
+        # request latency through the host entry point (vdb_search: H2D of the query, the same kernels,
+        # D2H of ids and scores), one blocking call at a time -- outside the timed region, on queries of
+        # its own
+        host_lat = None
+        if latency and world == 1 and nq == 1:
+            ncalls = 64
+            q_lat = torch.empty((ncalls, dim), dtype=torch.float32, device=dev)
+            eng.synth_fill_dev(q_lat.data_ptr(), ncalls, dim, seed=2, first_row=0, stream=stream.cuda_stream)
+            torch.cuda.synchronize()
+            q_host = q_lat.cpu().numpy()
+            lat = []
+            for i in range(ncalls):
+                one = q_host[i:i + 1]
+                assert one.shape[0] == 1
+                t1 = time.perf_counter()
+                eng.search(table, one, k)
+                lat.append((time.perf_counter() - t1) * 1e3)
+            lat = np.sort(np.array(lat[4:]))
+            host_lat = {"p50": float(np.percentile(lat, 50)), "p99": float(np.percentile(lat, 99)),
+                        "calls": int(lat.size), "what": "blocking vdb_search from host memory, one query per call"}
+
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        if world > 1 and args.backend == "nccl":
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elif world > 1:
+            tc = t.cpu()
+            dist.all_reduce(tc, op=dist.ReduceOp.MAX)
+            t = tc
+        elapsed = float(t.item())
+        q1, f1, b1 = eng.stats()
+        batched = b1 - b0
+
+        qps = steps * nq / elapsed
+        bytes_per_launch = n_local * dim * esz + (n_local * 4 if metric_name == "l2" else 0)
+        avg_s = (kern_ms / max(1, launches)) / 1e3
+        gbs = bytes_per_launch / avg_s / 1e9 if avg_s > 0 else 0.0
+        entry = {
+            "metric": "QPS top-%d %s, %dx%d %s, %s" % (k, metric_name, rows_total, dim, dtype,
+                                                      "single query" if nq == 1 else "batch %d" % nq),
+            "value": qps,
+            "unit": "QPS",
+            "ms_per_step": elapsed / steps * 1e3,
+            "steps": steps,
+            "warmup": warmup,
+            "dtype": "f32" if dtype == "f32" else dtype + " rows, f32 accumulate",
+            "workload": "%dx%d %s %s top-%d, nq=%d per step, rows sharded over %d GPU(s), exact ids+scores"
+                        % (rows_total, dim, dtype, metric_name, k, nq, world),
+            "rows_per_gpu": n_local,
+            "streams": n_streams,
+            "exact_fallbacks": f1 - f0,
+            "queries_counted": q1 - q0,
+            "roofline": {
+                "bound": "hbm", "kernel": "scan_kernel", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": gbs / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": bytes_per_launch,
+                "avg_launch_ms": avg_s * 1e3, "launches_timed": launches,
+            },
+            "host_latency_ms": host_lat,
+            "sample_result": {"ids": [int(x) for x in last_ids[0][:3]], "scores": [float(x) for x in last_scores[0][:3]]},
+        }
+        if batched > 0:
+            # batched path: the dominant kernel is the full pass of the MFMA kernel over all rows (one
+            # launch per 1024-query chunk); algorithmic flops = 2 * rows * dim * queries per launch
+            nq_launch = min(nq, 1024)
+            flops = 2.0 * n_local * dim * nq_launch
+            tf = flops / avg_s / 1e12 if avg_s > 0 else 0.0
+            if dtype == "f32" and opts.get("gemm32_split") == "0":
+                entry["roofline"] = {
+                    "bound": "mfma", "kernel": "gemm_thresh_kernel", "achieved": tf, "peak": MFMA_F32_PEAK_TF,
+                    "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF, "traffic": None,
+                    "flops_per_launch": flops, "avg_launch_ms": avg_s * 1e3, "launches_timed": launches,
+                }
+            else:
+                # every table type runs its batched passes on the 16-bit matrix unit: fp32 tables multiply
+                # a bf16 image of their rows (one product per term; gemm32_split=1: bf16 hi + lo, three
+                # products), 16-bit rows go in as stored (query rounded once, or hi + lo: two products).
+                # The ceiling for algorithmic flops is the dense 16-bit peak / products per term.
+                if dtype == "f32":
+                    products = 3 if opts.get("gemm32_split") == "1" else 1
+                    entry["dtype"] = ("f32 rows; fast pass bf16 hi+lo x3 on MFMA" if products == 3 else
+                                      "f32 rows; fast pass on their bf16 image on MFMA") + ", f32 accumulate; fp64 re-score"
+                else:
+                    products = 2 if opts.get("gemm_split_" + dtype) == "1" else 1
+                    entry["dtype"] = dtype + " rows on MFMA, f32 accumulate; fp64 re-score"
+                pp = nq_launch > 128 and products == 1 and opts.get("gemm_pp") != "0" and opts.get("bf16_mirror") != "0"
+                peak = MFMA_16_PEAK_TF / products
+                entry["roofline"] = {
+                    "bound": "mfma", "kernel": "gemm_pp_kernel" if pp else "gemm32s_kernel", "achieved": tf, "peak": peak,
+                    "unit": "TFLOP/s", "frac": tf / peak, "traffic": None,
+                    "flops_per_launch": flops, "mfma_flops_per_launch": products * flops,
+                    "avg_launch_ms": avg_s * 1e3, "launches_timed": launches,
+                    "row_bytes_per_launch": bytes_per_launch, "row_read_gbs_if_read_once": gbs,
+                }
+                if nq < 128:
+                    # less than one 128-query tile: the pass is bound by reading the rows once
+                    entry["roofline"].update({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                              "frac": gbs / HBM_PEAK_GBS, "bytes_per_launch": bytes_per_launch,
+                                              "algorithmic_tflops": tf})
+        # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE, runs of their own, gfx950
+        # half-count correction applied); only known for configurations that were profiled with the
+        # current kernels (the file names the commit)
+        try:
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+                tj = json.load(fh)
+            key = "%s|rows_per_gpu=%d|dim=%d|dtype=%s|nq=%d" % (entry["roofline"]["kernel"], n_local, dim, dtype, min(nq, 1024))
+            pmc = tj.get(key)
+            if pmc and not args.opt:
+                entry["roofline"]["traffic"] = pmc["hbm_read_bytes_per_launch"]
+                entry["roofline"]["traffic_source"] = pmc["source"]
+        except (OSError, ValueError):
+            pass
+        del queries
+        return entry
+
+    # ------------------------------------------------------------------ headline workload
+    dt, _ = DTYPES[args.dtype]
     metric = METRICS[args.metric]
     first, last = shard_range(args.rows, world, rank)
     n_local = last - first
@@ -136,169 +344,62 @@ def main() -> None:
     t_fill = time.perf_counter()
     eng.insert_synthetic(table, n_local, seed=0, first_row=first)
     t_fill = time.perf_counter() - t_fill
+    main_e = run_workload(table, args.rows, n_local, args.dim, args.dtype, args.metric, args.k, args.nq,
+                          args.steps, args.warmup, args.streams, latency=True)
 
-    total = args.steps + args.warmup
-    queries = torch.empty((total * args.nq, args.dim), dtype=torch.float32, device=dev)
-    stream = torch.cuda.current_stream()
-    eng.synth_fill_dev(queries.data_ptr(), total * args.nq, args.dim, seed=1, first_row=0, stream=stream.cuda_stream)
-    local_search, merge = gpu_backend(eng, table, args.nq, args.k, metric)
-    # batches keep the GPU busy on their own; single queries are pipelined over several streams
-    n_streams = max(1, args.streams) if args.nq == 1 else 1
-    searchers = [ShardedSearcher(args.nq, args.k, dev, local_search, merge) for _ in range(n_streams)]
-    streams = [stream] if n_streams == 1 else [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
-    torch.cuda.synchronize()
-
-    def step(i: int):
-        slot = i % n_streams
-        with torch.cuda.stream(streams[slot]):
-            return searchers[slot].search(queries[i * args.nq:(i + 1) * args.nq])
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for i in range(args.warmup):
-        step(i)
-    fence()
-    eng.prof_read()
-    eng.prof_enable(True)
-    t0 = time.perf_counter()
-    for i in range(args.warmup, total):
-        out = step(i)
-    fence()
-    elapsed = time.perf_counter() - t0
-    eng.prof_enable(False)
-    scan_ms, scan_launches = eng.prof_read()
-    last_ids = out.ids.cpu().numpy().copy()
-    last_scores = out.scores.cpu().numpy().copy()
-
-    # request latency through the host entry point (vdb_search: H2D of the query, the same kernels,
-    # D2H of ids and scores), one blocking call at a time -- outside the timed region
-    host_lat = None
-    if world == 1 and args.nq == 1:
-        q_host = queries[:64].cpu().numpy()
-        lat = []
-        for i in range(64):
-            t1 = time.perf_counter()
-            eng.search(table, q_host[i:i + 1], args.k)
-            lat.append((time.perf_counter() - t1) * 1e3)
-        lat = np.sort(np.array(lat[4:]))
-        host_lat = {"p50": float(np.percentile(lat, 50)), "p99": float(np.percentile(lat, 99)),
-                    "calls": int(lat.size), "what": "blocking vdb_search from host memory, one query per call"}
-
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-    queries_done, fallbacks, batched = eng.stats()
+    # ------------------------------------------------------------------ other BASELINE configurations
+    secondary = []
+    default_run = (args.rows == 10_000_000 and args.dim == 768 and args.dtype == "f32" and args.metric == "cosine"
+                   and args.nq == 1 and args.k == 10 and not args.opt)
+    if world == 1 and default_run and not args.no_secondary:
+        # batch 1024 on the same table (MFMA GEMM + fused top-k)
+        secondary.append(run_workload(table, args.rows, n_local, 768, "f32", "cosine", 10, 1024, 6, 2, 1, latency=False))
+        eng.drop_table(table)
+        for (rows, dim, dtype, mname, k, nq, steps, warmup, note) in (
+                (1_000_000, 768, "f32", "cosine", 10, 1, 200, 20, "1M x 768 fp32 single query"),
+                (12_500_000, 128, "bf16", "ip", 100, 1, 200, 20, "one shard of 8 of the 100M x 128 bf16 top-100 configuration"),
+                (20_000_000, 768, "f16", "l2", 10, 256, 6, 2, "20M of the 125M rows one GPU holds in the 1B x 768 fp16 L2 batch-256 configuration")):
+            name = "bench_%s_%d" % (dtype, rows)
+            eng.create_table(name, dim, METRICS[mname], DTYPES[dtype][0])
+            eng.reserve(name, rows)
+            eng.insert_synthetic(name, rows, seed=0, first_row=0)
+            e = run_workload(name, rows, rows, dim, dtype, mname, k, nq, steps, warmup, args.streams, latency=False)
+            e["note"] = note
+            secondary.append(e)
+            eng.drop_table(name)
 
     if rank == 0:
-        qps = args.steps * args.nq / elapsed
-        bytes_per_launch = n_local * args.dim * esz + (n_local * 4 if args.metric == "l2" else 0)
-        avg_scan_s = (scan_ms / max(1, scan_launches)) / 1e3
-        achieved = bytes_per_launch / avg_scan_s / 1e9 if avg_scan_s > 0 else 0.0
         line = {
-            "metric": "QPS top-%d %s, %dx%d %s, single query" % (args.k, args.metric, args.rows, args.dim, args.dtype)
-                      if args.nq == 1 else
-                      "QPS top-%d %s, %dx%d %s, batch %d" % (args.k, args.metric, args.rows, args.dim, args.dtype, args.nq),
-            "value": qps,
+            "metric": main_e["metric"],
+            "value": main_e["value"],
             "unit": "QPS",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": main_e["ms_per_step"],
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32" if args.dtype == "f32" else args.dtype + " rows, f32 accumulate",
+            "dtype": main_e["dtype"],
             "data": "synthetic (counter-hash ~N(0,1) embeddings generated on device, seed 0; queries seed 1)",
             "config": {
-                "workload": "%dx%d %s %s top-%d, nq=%d per step, rows sharded over %d GPU(s), exact ids+scores"
-                            % (args.rows, args.dim, args.dtype, args.metric, args.k, args.nq, world),
+                "workload": main_e["workload"],
                 "rows_per_gpu": n_local,
-                "parallelism": "row-shard x%d + RCCL all-gather of top-k records" % world if world > 1 else "single GPU",
-                "streams": n_streams,
+                "parallelism": "row-shard x%d + all-gather of top-k records" % world if world > 1 else "single GPU",
+                "backend": (args.backend + (" (RCCL)" if args.backend == "nccl" else "")) if world > 1 else "none",
+                "rccl_ranks": ranks_seen,
+                "streams": main_e["streams"],
                 "options": args.opt,
                 "table_fill_s": round(t_fill, 2),
-                "exact_fallbacks": fallbacks,
-                "queries_counted": queries_done,
+                "exact_fallbacks": main_e["exact_fallbacks"],
+                "queries_counted": main_e["queries_counted"],
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "scan_kernel",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
-                "bytes_per_launch": bytes_per_launch,
-                "avg_launch_ms": avg_scan_s * 1e3,
-                "launches_timed": scan_launches,
-            },
-            "host_latency_ms": host_lat,
-            "sample_result": {"ids": [int(x) for x in last_ids[0][:3]], "scores": [float(x) for x in last_scores[0][:3]]},
+            "roofline": main_e["roofline"],
+            "host_latency_ms": main_e["host_latency_ms"],
+            "sample_result": main_e["sample_result"],
         }
-        # HBM bytes per scan launch from the PMC pass (rocprofv3 --pmc FETCH_SIZE, a run of its own,
-        # gfx950 half-count correction applied); only known for configurations that were profiled
-        try:
-            with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
-                pmc = json.load(fh).get("scan_kernel|rows_per_gpu=%d|dim=%d|dtype=%s" % (n_local, args.dim, args.dtype))
-            if pmc and batched == 0:
-                line["roofline"]["traffic"] = pmc["hbm_read_bytes_per_launch"]
-                line["roofline"]["traffic_source"] = pmc["source"]
-        except (OSError, ValueError):
-            pass
-        if batched > 0:
-            # batched path: the dominant kernel is the MFMA GEMM of the last threshold pass over all rows
-            # (one launch per 1024-query chunk); algorithmic flops = 2 * rows * dim * queries per launch
-            nq_launch = min(args.nq, 1024)
-            flops = 2.0 * n_local * args.dim * nq_launch
-            tf = flops / avg_scan_s / 1e12 if avg_scan_s > 0 else 0.0
-            opts = dict(o.split("=", 1) for o in args.opt)
-            if args.dtype == "f32" and opts.get("gemm32_split") == "0":
-                line["roofline"] = {
-                    "bound": "mfma", "kernel": "gemm_thresh_kernel", "achieved": tf, "peak": MFMA_F32_PEAK_TF,
-                    "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF, "traffic": None,
-                    "flops_per_launch": flops, "avg_launch_ms": avg_scan_s * 1e3, "launches_timed": scan_launches,
-                }
-            else:
-                # every table type runs its batched passes on the 16-bit matrix unit: fp32 rows rounded
-                # to bf16 on the way to LDS (one product per term; gemm32_split=1: bf16 hi + lo, three
-                # products), 16-bit rows as stored (query rounded once, or hi + lo: two products).  The
-                # ceiling for algorithmic flops is the dense 16-bit peak / products per term.
-                if args.dtype == "f32":
-                    products = 3 if opts.get("gemm32_split") == "1" else 1
-                    line["dtype"] = ("f32 rows; fast pass bf16 hi+lo x3 on MFMA" if products == 3 else
-                                     "f32 rows; fast pass rounded to bf16 on MFMA") + ", f32 accumulate; fp64 re-score"
-                else:
-                    products = 2 if opts.get("gemm_split_" + args.dtype) == "1" else 1
-                    line["dtype"] = args.dtype + " rows on MFMA, f32 accumulate; fp64 re-score"
-                peak = 2500.0 / products
-                line["roofline"] = {
-                    "bound": "mfma", "kernel": "gemm32s_kernel", "achieved": tf, "peak": peak,
-                    "unit": "TFLOP/s", "frac": tf / peak, "traffic": None,
-                    "flops_per_launch": flops, "mfma_flops_per_launch": products * flops,
-                    "avg_launch_ms": avg_scan_s * 1e3, "launches_timed": scan_launches,
-                    "row_bytes_per_launch": bytes_per_launch, "row_read_gbs_if_read_once": achieved,
-                }
-                if args.nq < 128:
-                    # less than one 128-query tile: the pass is bound by reading the rows once
-                    line["roofline"].update({"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                             "frac": achieved / HBM_PEAK_GBS, "bytes_per_launch": bytes_per_launch,
-                                             "algorithmic_tflops": tf})
-            try:
-                with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
-                    pmc = json.load(fh).get("%s|rows_per_gpu=%d|dim=%d|dtype=%s|nq=%d" % (
-                        line["roofline"]["kernel"], n_local, args.dim, args.dtype, nq_launch))
-                if pmc and not args.opt:
-                    # HBM bytes per launch of the full pass (own --pmc FETCH_SIZE run): the query tiles of
-                    # one row range share the rows through L2, so this stays near one read of the table
-                    line["roofline"]["traffic"] = pmc["hbm_read_bytes_per_launch"]
-                    line["roofline"]["traffic_source"] = pmc["source"]
-            except (OSError, ValueError):
-                pass
+        if secondary:
+            line["secondary"] = secondary
         if world == 1 and args.cpu_seconds > 0 and args.nq == 1:
             line["cpu_baseline"] = cpu_baseline(args.rows, args.dim, args.k, args.metric, args.cpu_seconds)
         print(json.dumps(line), flush=True)
