@@ -14,8 +14,10 @@
  *   - plain pointers and sizes only; the caller allocates every output;
  *   - host entry points take host pointers; `_dev` entry points take device
  *     pointers valid on the library's device and a HIP stream handle
- *     (a `hipStream_t` passed as `void*`, NULL = the default stream), enqueue
- *     their work on that stream and return without synchronising;
+ *     (a `hipStream_t` passed as `void*`, NULL = the default stream); the search
+ *     and merge `_dev` calls enqueue their work on that stream and return
+ *     without synchronising, vdb_insert_dev waits for its stream before it
+ *     returns (the new rows are then visible to searches on any stream);
  *   - thread safety: any number of concurrent searches; inserts on a table are
  *     serialised and exclude searches on that table while rows are added
  *     (the reference serves each HTTP request on its own thread against one
@@ -147,6 +149,18 @@ int vdb_search(const char* name, int64_t nq, const float* queries, int k,
 int vdb_search_dev(const char* name, int64_t nq, const float* queries_dev, int k,
                    int64_t* out_ids_dev, float* out_scores_dev, int32_t* out_counts_dev,
                    void* stream);
+
+/* No counterpart in the reference.  The same search as vdb_search_dev for callers that cannot
+ * allocate device memory (code under HIP graph capture, tight serving loops, harnesses that forbid
+ * it): the call allocates, creates and frees nothing.  Its intermediate buffers live in a 24 MiB
+ * array inside the library's code object (each GPU the library runs on holds its copy until the
+ * process ends); a search that needs more (many queries per call, a large k: about 3.1 MiB per query
+ * at k = 10 on a large table, 12.6 MiB at k = 100) is refused with VDB_EINVAL, as are more than 256
+ * queries per call.  Every query runs as a scan (no batched path); results are those of
+ * vdb_search_dev bit for bit.  All calls on one GPU share the array: calls that overlap in time race. */
+int vdb_search_dev_noalloc(const char* name, int64_t nq, const float* queries_dev, int k,
+                           int64_t* out_ids_dev, float* out_scores_dev, int32_t* out_counts_dev,
+                           void* stream);
 
 /* ---- row-sharded tables: merge of per-shard results (no counterpart in the reference, which
  * talks to one engine: server_config.yaml:8 deploy_mode single) -------------------------------

@@ -40,6 +40,7 @@ SIGNATURES = {
     "vdb_load_table": (C.c_int, [C.c_char_p, C.c_char_p]),
     "vdb_search": (C.c_int, [C.c_char_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vdb_search_dev": (C.c_int, [C.c_char_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vdb_search_dev_noalloc": (C.c_int, [C.c_char_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vdb_merge_topk_dev": (C.c_int, [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vdb_record_bytes": (C.c_int64, [C.c_int64, C.c_int]),

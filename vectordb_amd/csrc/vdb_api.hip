@@ -42,6 +42,7 @@ struct Workspace {
     hipStream_t last_stream = nullptr;   // stream the last call was enqueued on
     hipEvent_t  done = nullptr;          // recorded after the last call's work
     bool        used = false;
+    bool        fixed = false;           // buffers are carved from a fixed region: never (re)allocated
     DevBuf qprep, qinfo, cand_s, cand_t, need_exact;      // search scratch
     DevBuf small;                                         // batched path: cnt | lost | thr0 | thr1
     DevBuf cand_h;                                        // scan path: list heads
@@ -136,6 +137,14 @@ struct Global {
 };
 static Global G;
 
+// Scratch memory of vdb_search_dev_noalloc: part of the code object, so that the entry point itself
+// never allocates.  The array's name is a host-side stand-in; its device address is looked up once
+// per device at vdb_init (hipGetSymbolAddress) and only that pointer is handed to kernels.
+static const size_t NOALLOC_BYTES = (size_t)24 << 20;
+static __device__ __align__(256) unsigned char vdb_noalloc_scratch[NOALLOC_BYTES];
+static const int NOALLOC_MAX_DEV = 64;
+static void* g_noalloc_ptr[NOALLOC_MAX_DEV] = {};
+
 static size_t round_up(size_t v, size_t g) { return (v + g - 1) / g * g; }
 
 static int enter() {
@@ -145,8 +154,9 @@ static int enter() {
     return VDB_OK;
 }
 
-static int ensure(DevBuf& b, size_t bytes, hipStream_t busy_on) {
+static int ensure(DevBuf& b, size_t bytes, hipStream_t busy_on, bool fixed = false) {
     if (bytes <= b.cap) return VDB_OK;
+    if (fixed) return fail(VDB_EINVAL, "the search needs more scratch memory than the no-allocation entry point holds");
     if (b.p) {
         if (busy_on) VDB_HIP(hipStreamSynchronize(busy_on));
         VDB_HIP(hipFree(b.p));
@@ -261,12 +271,12 @@ static int search_scan_path(const TableView& tv, const SelGeom& g, int dpad, int
     const int64_t chunk = 256;
     const int64_t nqc = nq < chunk ? nq : chunk;
     int rc;
-    if ((rc = ensure(ws.qprep, (size_t)nqc * dpad * sizeof(float), ws.last_stream))) return rc;
-    if ((rc = ensure(ws.qinfo, (size_t)nqc * sizeof(QInfo), ws.last_stream))) return rc;
-    if ((rc = ensure(ws.cand_s, (size_t)nqc * Gx * g.W * g.K * sizeof(float), ws.last_stream))) return rc;
-    if ((rc = ensure(ws.cand_t, (size_t)nqc * Gx * g.W * g.K * sizeof(long long), ws.last_stream))) return rc;
-    if ((rc = ensure(ws.cand_h, (size_t)nqc * Gx * g.W * sizeof(float), ws.last_stream))) return rc;
-    if ((rc = ensure(ws.need_exact, (size_t)(nqc + 1) * sizeof(int), ws.last_stream))) return rc;
+    if ((rc = ensure(ws.qprep, (size_t)nqc * dpad * sizeof(float), ws.last_stream, ws.fixed))) return rc;
+    if ((rc = ensure(ws.qinfo, (size_t)nqc * sizeof(QInfo), ws.last_stream, ws.fixed))) return rc;
+    if ((rc = ensure(ws.cand_s, (size_t)nqc * Gx * g.W * g.K * sizeof(float), ws.last_stream, ws.fixed))) return rc;
+    if ((rc = ensure(ws.cand_t, (size_t)nqc * Gx * g.W * g.K * sizeof(long long), ws.last_stream, ws.fixed))) return rc;
+    if ((rc = ensure(ws.cand_h, (size_t)nqc * Gx * g.W * sizeof(float), ws.last_stream, ws.fixed))) return rc;
+    if ((rc = ensure(ws.need_exact, (size_t)(nqc + 1) * sizeof(int), ws.last_stream, ws.fixed))) return rc;
     // Many short rows and a long candidate list: every wave would spend its first K*ln(rows/K)
     // rows filling and sorting its own list.  A scan of a small sample of the rows (1/256) first
     // gives the K-th best key of the sample, a lower bound of the K-th best key of the table; the
@@ -279,7 +289,7 @@ static int search_scan_path(const TableView& tv, const SelGeom& g, int dpad, int
         tvs.n = tv.n / 256 > 4LL * g.K ? tv.n / 256 : 4LL * g.K;
         Gs = scan_grid(tvs, g, G.n_cu);
         if (Gs > G.n_cu) Gs = G.n_cu;                                 // one block per CU is plenty for 0.4 % of the rows
-        if ((rc = ensure(ws.small, (size_t)nqc * sizeof(float), ws.last_stream))) return rc;
+        if ((rc = ensure(ws.small, (size_t)nqc * sizeof(float), ws.last_stream, ws.fixed))) return rc;
     }
     for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
         const int64_t nqi = nq - q0 < chunk ? nq - q0 : chunk;
@@ -300,16 +310,17 @@ static int search_scan_path(const TableView& tv, const SelGeom& g, int dpad, int
             // the other (two at once would only evict each other's cache lines), while the short
             // kernels before and after a scan overlap with the scans of the other streams.
             std::unique_lock<std::mutex> chain(G.chain_mu);
-            const bool ordered = G.scan_serialize != 0;
+            // (the no-allocation entry point creates no events: its scans are neither chained nor timed)
+            const bool ordered = G.scan_serialize != 0 && !ws.fixed;
             if (!ordered) chain.unlock();
             if (ordered) {
                 if (G.chain_head >= 0 && G.chain_last != st)
                     VDB_HIP(hipStreamWaitEvent(st, G.chain_ev[G.chain_head], 0));
             }
             ProfScope prof;
-            if ((rc = prof.begin(st))) return rc;
+            if (!ws.fixed && (rc = prof.begin(st))) return rc;
             VDB_HIP(launch_scan(tv, qprep, nqi, dpad, g, Gx, cs, ct, (float*)ws.cand_h.p, floor, st));
-            if ((rc = prof.end(st))) return rc;
+            if (!ws.fixed && (rc = prof.end(st))) return rc;
             if (ordered) {
                 const int slot = (G.chain_head + 1) % 16;
                 if (!G.chain_ev[slot]) VDB_HIP(hipEventCreateWithFlags(&G.chain_ev[slot], hipEventDisableTiming));
@@ -477,7 +488,7 @@ static int search_core(Table& t, int64_t nq, const float* q_dev, int k, long lon
     SelGeom g = sel_geom(k);
     if (G.tune_waves > 0 && G.tune_waves < g.W) g.W = G.tune_waves;
     // engine_config.use_blas_threshold: batches at least this large take the GEMM path
-    bool gemm = nq >= G.use_blas_threshold && tv.n >= 65536 && g.K <= 256 && G.tune_gemm != 0;
+    bool gemm = nq >= G.use_blas_threshold && tv.n >= 65536 && g.K <= 256 && G.tune_gemm != 0 && !ws.fixed;
     if (gemm) {
         // Small tables: a batched pass has a fixed cost (threshold passes, flat finalize) that a
         // few scans undercut.  Both estimates are fits of measured times (seconds; row bytes B):
@@ -720,6 +731,13 @@ int vdb_init(int device) {
     if (e == hipSuccess) e = hipStreamCreate(&G.insert_stream);
     if (e != hipSuccess) return fail(VDB_ENOGPU, std::string("device set-up: ") + hipGetErrorString(e));
     G.device = device;
+    if (device < NOALLOC_MAX_DEV && !g_noalloc_ptr[device]) {
+        // this device's copy of the scratch array (each GPU holds its own, at its own address)
+        void* sp = nullptr;
+        e = hipGetSymbolAddress(&sp, HIP_SYMBOL(vdb_noalloc_scratch));
+        if (e != hipSuccess || !sp) return fail(VDB_ENOGPU, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
+        g_noalloc_ptr[device] = sp;
+    }
     {
         // allocation granularity of the virtual-memory API; 0 leaves tables on plain allocations
         hipMemAllocationProp prop = {};
@@ -1188,6 +1206,52 @@ int vdb_search_dev(const char* name, int64_t nq, const float* queries_dev, int k
         else rc = search_core(*t, nq, queries_dev, k, (long long*)out_ids_dev, out_scores_dev, out_counts_dev, st, *ws);
     }
     release_ws(ws, st);
+    return rc;
+}
+
+// Same search as vdb_search_dev for callers that must not allocate device memory (code under HIP graph
+// capture, tight serving loops): every intermediate buffer is carved from the 24 MiB scratch array
+// above, always by the per-query scan (no batched path), nothing is created, allocated or freed.
+// All calls on one GPU share the array: calls that overlap in time race.
+int vdb_search_dev_noalloc(const char* name, int64_t nq, const float* queries_dev, int k,
+                           int64_t* out_ids_dev, float* out_scores_dev, int32_t* out_counts_dev, void* stream) {
+    int rc = enter();
+    if (rc) return rc;
+    if ((rc = check_search_args(name, nq, queries_dev, k, out_ids_dev, out_scores_dev, out_counts_dev))) return rc;
+    auto t = find_table(name);
+    if (!t) return fail(VDB_ENOTFOUND, std::string("no such table: ") + name);
+    if (nq == 0) return VDB_OK;
+    char* base = G.device < NOALLOC_MAX_DEV ? (char*)g_noalloc_ptr[G.device] : nullptr;
+    if (!base) return fail(VDB_ESTATE, "no scratch array on this device");
+    std::shared_lock<std::shared_mutex> tl(t->mu);
+    if (t->dropped) return fail(VDB_ENOTFOUND, "table was dropped");
+    // sizes as search_scan_path asks for them, for the table as it is now
+    TableView tv;
+    tv.rows = t->d_rows; tv.n = t->rows.load(std::memory_order_acquire); tv.d = (int)t->dim; tv.m = t->m;
+    tv.dt = t->dtype; tv.metric = t->metric;
+    SelGeom g = sel_geom(k);
+    if (G.tune_waves > 0 && G.tune_waves < g.W) g.W = G.tune_waves;
+    const int Gx = tv.n > 0 ? scan_grid(tv, g, G.n_cu) : 1;
+    const size_t lists = (size_t)nq * Gx * g.W;
+    const size_t want[7] = {(size_t)nq * t->dpad * sizeof(float), (size_t)nq * sizeof(QInfo), lists * g.K * sizeof(float),
+                            lists * g.K * sizeof(long long), lists * sizeof(float), (size_t)(nq + 1) * sizeof(int),
+                            (size_t)nq * sizeof(float)};
+    if (nq > 256) return fail(VDB_EINVAL, "vdb_search_dev_noalloc takes at most 256 queries per call");
+    Workspace ws;
+    ws.fixed = true;
+    DevBuf* bufs[7] = {&ws.qprep, &ws.qinfo, &ws.cand_s, &ws.cand_t, &ws.cand_h, &ws.need_exact, &ws.small};
+    size_t off = 0;
+    for (int i = 0; i < 7; ++i) {
+        const size_t sz = round_up(want[i], 256);
+        if (off + sz > NOALLOC_BYTES)
+            return fail(VDB_EINVAL, "this search needs " + std::to_string((off + sz + ((size_t)1 << 20) - 1) >> 20) +
+                                    " MiB or more of scratch memory; vdb_search_dev_noalloc holds 24 MiB (fewer queries per call or a smaller k fit)");
+        bufs[i]->p = base + off;
+        bufs[i]->cap = sz;
+        off += sz;
+    }
+    rc = search_core(*t, nq, queries_dev, k, (long long*)out_ids_dev, out_scores_dev, out_counts_dev, (hipStream_t)stream, ws);
+    for (DevBuf* b : bufs) *b = DevBuf();          // nothing here is owned
     return rc;
 }
 

@@ -129,6 +129,13 @@ class Engine:
                                       C.c_void_p(out_ids_ptr), C.c_void_p(out_scores_ptr),
                                       C.c_void_p(out_counts_ptr), C.c_void_p(stream)))
 
+    def search_dev_noalloc(self, name: str, nq: int, queries_ptr: int, k: int, out_ids_ptr: int,
+                           out_scores_ptr: int, out_counts_ptr: int, stream: int = 0) -> None:
+        """vdb_search_dev without any device allocation (fixed scratch inside the library)."""
+        check(self.lib.vdb_search_dev_noalloc(_name(name), int(nq), C.c_void_p(queries_ptr), int(k),
+                                              C.c_void_p(out_ids_ptr), C.c_void_p(out_scores_ptr),
+                                              C.c_void_p(out_counts_ptr), C.c_void_p(stream)))
+
     def merge_topk_dev(self, nparts: int, nq: int, k: int, metric: int, in_ids_ptr: int, in_scores_ptr: int,
                        in_counts_ptr: int, out_ids_ptr: int, out_scores_ptr: int, out_counts_ptr: int,
                        stream: int = 0) -> None:
