@@ -12,10 +12,15 @@ MI355X engine.  Same wire format (curl-com.txt:1: PUT, JSON body {"name", "vecto
 The engine client is the `milvus` module of this repository (the reference's import line,
 app.py:3, unchanged); the relational side is server/metastore.py instead of a Postgres server.
 
+/lookup answers what the reference answers: the exact-match asset list is attached to every hit
+(app.py:431 appends `assets_ids`, the exact-match list, where each hit's own `asset_ids` was
+probably meant).  VDB_COMPAT_LOOKUP_BUG=0 (or create_app(compat_lookup=False)) attaches each hit's
+own asset ids instead.
+
 Differences from the reference, on purpose:
-  * /lookup returns each hit's own asset ids.  The reference appends the exact-match list to
-    every hit (app.py:431 uses `assets_ids` where `asset_ids` was meant); set
-    VDB_COMPAT_LOOKUP_BUG=1 to reproduce that output.
+  * an engine call that fails is reported (4xx/5xx with the status message) and leaves no
+    bookkeeping behind; the reference ignores the statuses of create_table and insert
+    (app.py:143,149,325), so a refused vector would stay recorded as known and never be stored.
   * /lookup accepts optional ?k= (default 10, as hard-coded at app.py:426) and a JSON body with
     "vectors": [[...], ...] for a batch (answers a list of result lists).
   * database names are validated instead of being concatenated into SQL.
@@ -30,7 +35,7 @@ import threading
 from flask import Flask, request
 
 from milvus import IndexType, MetricType, Milvus
-from server.metastore import MetaStore, MetaStoreError
+from server.metastore import MetaStore, MetaStoreError, check_name
 from vectordb_amd.cluster import ClusterMilvus
 from vectordb_amd.config import load_config
 from vectordb_amd.hashing import hash_vector
@@ -41,11 +46,11 @@ _INDEX_FILE_SIZE = 32
 _METRICS = {"ip": MetricType.IP, "l2": MetricType.L2, "cosine": MetricType.COSINE}
 
 
-def create_app(client: Milvus = None, store: MetaStore = None) -> Flask:
+def create_app(client: Milvus = None, store: MetaStore = None, compat_lookup: bool = None) -> Flask:
     app = Flask(__name__)
     state = {"client": client, "store": store or MetaStore(os.environ.get("VDB_META_PATH", ":memory:"))}
     lock = threading.Lock()
-    compat_bug = os.environ.get("VDB_COMPAT_LOOKUP_BUG", "0") == "1"
+    compat_bug = (os.environ.get("VDB_COMPAT_LOOKUP_BUG", "1") != "0") if compat_lookup is None else bool(compat_lookup)
 
     def engine() -> Milvus:
         with lock:
@@ -69,9 +74,17 @@ def create_app(client: Milvus = None, store: MetaStore = None) -> Flask:
         status, exists = engine().has_table(name)
         if exists:
             return -1, "Error: table with name: " + name + " exists in milvus (but not in postgres)"
-        store_().create_db(name, dimensions, index_type, metric)
-        engine().create_table({"table_name": name, "dimension": dimensions, "index_file_size": _INDEX_FILE_SIZE,
-                               "metric_type": _METRICS[metric], "dtype": dtype})
+        check_name(name)
+        # the engine table first: a refused table (dimension out of range, HBM budget) leaves no record
+        status = engine().create_table({"table_name": name, "dimension": dimensions, "index_file_size": _INDEX_FILE_SIZE,
+                                        "metric_type": _METRICS[metric], "dtype": dtype})
+        if not status.OK():
+            return -2, "Error: " + status.message
+        try:
+            store_().create_db(name, dimensions, index_type, metric)
+        except Exception:
+            engine().delete_table(name)
+            raise
         engine().create_index(name, {"index_type": IndexType.IVFLAT, "nlist": 2048})
         return 1, "Vector database with name: " + name + " created"
 
@@ -112,7 +125,7 @@ def create_app(client: Milvus = None, store: MetaStore = None) -> Flask:
             if metric not in _METRICS:
                 return "Error: unknown metric " + metric, 400
             code, text = create_vector_db(name, dimensions, metric, dtype)
-            return text
+            return (text, 400) if code == -2 else text
         except (MetaStoreError, TypeError, ValueError) as exc:
             return "Error: " + str(exc), 400
 
@@ -153,7 +166,12 @@ def create_app(client: Milvus = None, store: MetaStore = None) -> Flask:
         except (MetaStoreError, Exception) as exc:      # unknown database etc.
             return "Error: " + str(exc), 400
         if is_new:
-            engine().insert(name, records=[vector], ids=[vector_hash])
+            result = engine().insert(name, records=[vector], ids=[vector_hash])
+            status = result[0] if isinstance(result, tuple) else result
+            if not status.OK():
+                # the vector is not stored: forget the mapping, or every retry would find the hash known
+                store_().remove_mapping(name, vector_hash, asset_id)
+                return "Error: " + status.message, 500
         return "hej"                                     # app.py:349
 
     @app.route("/lookupexact", methods=["PUT"])

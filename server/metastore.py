@@ -77,6 +77,12 @@ class MetaStore:
                              (vector_hash, str(asset_id)))
             return not known
 
+    def remove_mapping(self, name: str, vector_hash: int, asset_id: str) -> None:
+        """Undo add_mapping (the engine refused the vector that belongs to it)."""
+        check_name(name)
+        with self._lock, self._db:
+            self._db.execute("DELETE FROM %s WHERE vector_hash = ? AND asset_id = ?" % name, (vector_hash, str(asset_id)))
+
     def assets(self, name: str, vector_hash: int) -> List[str]:
         check_name(name)
         with self._lock:

@@ -50,7 +50,8 @@ def test_client_shim_as_the_reference_calls_it(engine):
 def test_http_routes_over_the_engine(engine):
     from server.app import create_app
     from server.metastore import MetaStore
-    http = create_app(store=MetaStore()).test_client()
+    http = create_app(store=MetaStore(), compat_lookup=False).test_client()      # each hit with its own asset ids
+    ref_http = None
     name, d, n = "httpdb", 384, 400
     http.get("/deletedb?dbname=" + name)
     assert "created" in http.get("/createdb?dbname=%s&dimensions=%d&metric=cosine" % (name, d)).get_data(as_text=True)
@@ -73,12 +74,96 @@ def test_http_routes_over_the_engine(engine):
             idx = int(np.nonzero(ids == want_id)[0][0])
             assert hit["asset_ids"] == (["v3", "alias"] if idx == 3 else ["v%d" % idx])
             assert np.float32(hit["distance"]) == want_sc
+    # batched body and ?k=: hit by hit against the oracle
     batch = json.loads(http.put("/lookup?dbname=%s&k=5" % name, json={"vectors": queries}).get_data())
-    assert len(batch) == 2 and all(len(b) == 6 for b in batch)
+    assert len(batch) == 2
+    want5 = O.search(stored, ids, np.array(queries, dtype=np.float32), 5, O.COSINE)
+    for out, (wi, ws), q in zip(batch, want5, queries):
+        assert out[0] == {"distance": 0, "asset_ids": ["v3", "alias"] if q is vecs[3] else []}
+        assert len(out) == 6
+        for hit, want_id, want_sc in zip(out[1:], wi, ws):
+            idx = int(np.nonzero(ids == want_id)[0][0])
+            assert hit["asset_ids"] == (["v3", "alias"] if idx == 3 else ["v%d" % idx])
+            assert np.float32(hit["distance"]) == want_sc
     assert json.loads(http.put("/lookupexact?dbname=" + name, json={"vector": vecs[3]}).get_data()) == ["v3", "alias"]
     assert http.get("/checkintegrity").get_data(as_text=True) == "All ok"
     assert http.get("/deletedb?dbname=" + name).get_data(as_text=True) == "Table deleted"
     assert not engine.has_table(name)
+
+
+def test_lookup_default_output_is_the_reference_s(engine):
+    """/root/reference/app.py:431 attaches the exact-match asset list to every hit: the default output
+    does the same (same distances, same number of entries), compat_lookup=False gives each hit its own."""
+    from server.app import create_app
+    from server.metastore import MetaStore
+    store = MetaStore()
+    ref = create_app(store=store).test_client()
+    own = create_app(store=store, compat_lookup=False).test_client()
+    name, d = "httpref", 16
+    ref.get("/deletedb?dbname=" + name)
+    assert "created" in ref.get("/createdb?dbname=%s&dimensions=%d" % (name, d)).get_data(as_text=True)
+    rng = np.random.default_rng(5)
+    vecs = [rng.random(d).tolist() for _ in range(40)]
+    for i, v in enumerate(vecs):
+        assert ref.put("/insert?dbname=" + name, json={"name": "a%d" % i, "vector": v}).get_data(as_text=True) == "hej"
+    a = json.loads(ref.put("/lookup?dbname=" + name, json={"vector": vecs[7]}).get_data())
+    b = json.loads(own.put("/lookup?dbname=" + name, json={"vector": vecs[7]}).get_data())
+    assert [h["distance"] for h in a] == [h["distance"] for h in b] and len(a) == 11
+    assert all(h["asset_ids"] == ["a7"] for h in a)                 # the exact-match list on every line
+    assert b[1]["asset_ids"] == ["a7"] and any(h["asset_ids"] != ["a7"] for h in b[2:])
+    assert ref.get("/deletedb?dbname=" + name).get_data(as_text=True) == "Table deleted"
+
+
+@pytest.mark.parametrize("dtype,metric", [("bf16", "l2"), ("f16", "l2"), ("bf16", "ip"), ("f16", "cosine")])
+def test_http_reduced_precision_tables_and_metrics(engine, dtype, metric):
+    """/createdb?...&dtype=&metric= followed by /insert and /lookup (single and batched, ?k=): ids and
+    distances are the oracle's for rows rounded to the table's storage type."""
+    from server.app import create_app
+    from server.metastore import MetaStore
+    http = create_app(store=MetaStore(), compat_lookup=False).test_client()
+    name, d, n, k = "http_%s_%s" % (dtype, metric), 48, 300, 7
+    http.get("/deletedb?dbname=" + name)
+    r = http.get("/createdb?dbname=%s&dimensions=%d&metric=%s&dtype=%s" % (name, d, metric, dtype))
+    assert "created" in r.get_data(as_text=True)
+    rng = np.random.default_rng(17)
+    vecs = [(rng.random(d) - 0.5).tolist() for _ in range(n)]
+    for i, v in enumerate(vecs):
+        assert http.put("/insert?dbname=" + name, json={"name": "v%d" % i, "vector": v}).get_data(as_text=True) == "hej"
+    info = engine.table_info(name)
+    assert info["rows"] == n and info["dtype"] == cases.DTYPES[dtype] and info["metric"] == cases.METRICS[metric]
+    ids = np.array([O.hash_vector(v) for v in vecs], dtype=np.int64)
+    stored = O.prepare_store(np.asarray(vecs, dtype=np.float32), cases.METRICS[metric], cases.DTYPES[dtype])
+    queries = [vecs[11], (np.random.default_rng(18).random(d) - 0.5).tolist(), vecs[200]]
+    want = O.search(stored, ids, np.array(queries, dtype=np.float32), k, cases.METRICS[metric])
+    batch = json.loads(http.put("/lookup?dbname=%s&k=%d" % (name, k), json={"vectors": queries}).get_data())
+    assert len(batch) == len(queries)
+    for qi, (out, (wi, ws)) in enumerate(zip(batch, want)):
+        single = json.loads(http.put("/lookup?dbname=%s&k=%d" % (name, k), json={"vector": queries[qi]}).get_data())
+        assert single == out
+        assert len(out) == k + 1
+        for hit, want_id, want_sc in zip(out[1:], wi, ws):
+            idx = int(np.nonzero(ids == want_id)[0][0])
+            assert hit["asset_ids"] == ["v%d" % idx]
+            assert np.float32(hit["distance"]) == want_sc
+    assert http.get("/deletedb?dbname=" + name).get_data(as_text=True) == "Table deleted"
+
+
+def test_http_insert_of_a_vector_the_engine_refuses(engine):
+    """A vector with a value that is not finite: the engine refuses it, /insert answers 500 and the hash
+    is not recorded, so nothing is half stored."""
+    from server.app import create_app
+    from server.metastore import MetaStore
+    store = MetaStore()
+    http = create_app(store=store).test_client()
+    name = "httpnan"
+    http.get("/deletedb?dbname=" + name)
+    http.get("/createdb?dbname=%s&dimensions=4&dtype=f16" % name)
+    assert http.put("/insert?dbname=" + name, json={"name": "ok", "vector": [1.0, 2.0, 3.0, 4.0]}).get_data(as_text=True) == "hej"
+    r = http.put("/insert?dbname=" + name, json={"name": "big", "vector": [1.0, 1e6, 3.0, 4.0]})      # overflows fp16
+    assert r.status_code == 500 and "finite" in r.get_data(as_text=True)
+    assert engine.count(name) == 1
+    assert store.assets(name, O.hash_vector([1.0, 1e6, 3.0, 4.0])) == []
+    http.get("/deletedb?dbname=" + name)
 
 
 def test_concurrent_lookups_are_merged_and_stay_exact(engine):

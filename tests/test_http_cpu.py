@@ -49,7 +49,7 @@ class RecordingClient:
 @pytest.fixture
 def svc():
     client = RecordingClient()
-    app = create_app(client=client, store=MetaStore())
+    app = create_app(client=client, store=MetaStore(), compat_lookup=False)     # each hit with its own asset ids
     return app.test_client(), client
 
 
@@ -89,6 +89,53 @@ def test_createdb_insert_lookup_flow(svc):
     assert client.searches[-1] == ("test", [body["vector"]], 10, 10)      # k and nprobe of app.py:384-389,426
     out = json.loads(http.put("/lookup?dbname=test&k=3", json={"vectors": [body["vector"], other["vector"]]}).get_data())
     assert client.searches[-1][2] == 3 and out == []           # canned result count != batch size
+
+
+def test_lookup_answers_as_the_reference_does_by_default():
+    """/root/reference/app.py:431 appends the exact-match asset list to every hit; that output is the
+    default, each hit's own asset ids the option (VDB_COMPAT_LOOKUP_BUG=0 / compat_lookup=False)."""
+    client = RecordingClient()
+    http = create_app(client=client, store=MetaStore()).test_client()
+    http.get("/createdb?dbname=test&dimensions=4")
+    a, b = {"name": "a", "vector": [0.1, 0.2, 0.3, 0.4]}, {"name": "b", "vector": [0.5] * 4}
+    http.put("/insert?dbname=test", json=a)
+    http.put("/insert?dbname=test", json=b)
+    client.next_results = [[QueryResult(hash_vector(a["vector"]), 2.0), QueryResult(hash_vector(b["vector"]), 1.0)]]
+    out = json.loads(http.put("/lookup?dbname=test", json=a).get_data())
+    assert out == [{"distance": 0, "asset_ids": ["a"]}, {"distance": 2.0, "asset_ids": ["a"]},
+                   {"distance": 1.0, "asset_ids": ["a"]}]
+
+
+class RefusingClient(RecordingClient):
+    """An engine that refuses what it is asked to store (HBM budget exhausted, a value that is not
+    finite, a lost worker)."""
+    refuse_create = False
+
+    def create_table(self, param):
+        if self.refuse_create:
+            return Status(-1, "dimension must be in [1, 16384]")
+        return super().create_table(param)
+
+    def insert(self, name, records, ids):
+        return Status(-6, "table storage would exceed gpu_resource_config.cache_capacity"), []
+
+
+def test_engine_failures_are_reported_and_leave_no_bookkeeping():
+    client = RefusingClient()
+    store = MetaStore()
+    http = create_app(client=client, store=store).test_client()
+    client.refuse_create = True
+    r = http.get("/createdb?dbname=big&dimensions=99999")
+    assert r.status_code == 400 and "dimension" in r.get_data(as_text=True)
+    assert not store.has_db("big")
+    client.refuse_create = False
+    assert "created" in http.get("/createdb?dbname=t&dimensions=4").get_data(as_text=True)
+    body = {"name": "a", "vector": [0.1, 0.2, 0.3, 0.4]}
+    r = http.put("/insert?dbname=t", json=body)
+    assert r.status_code == 500 and "cache_capacity" in r.get_data(as_text=True)
+    # the hash is not left behind as known: a retry reaches the engine again
+    assert store.assets("t", hash_vector(body["vector"])) == []
+    assert store.add_mapping("t", hash_vector(body["vector"]), "a") is True
 
 
 def test_deletedb_and_integrity(svc):

@@ -5,7 +5,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvdb.so")
+# VDB_LIBRARY names another build of the same library (A/B runs of kernel variants)
+LIB_PATH = os.environ.get("VDB_LIBRARY") or os.path.join(_HERE, "libvdb.so")
 
 OK = 0
 EINVAL, ENOTFOUND, EEXISTS, ENOGPU, EHIP, ENOMEM, ESTATE = -1, -2, -3, -4, -5, -6, -7

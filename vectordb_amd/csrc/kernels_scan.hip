@@ -67,6 +67,23 @@ __device__ __forceinline__ float dot_unit(const u32x4& x, const float* q, float 
     return acc;
 }
 
+// bf16 rows against a query held as packed bf16 hi + lo parts (q ~ qh + ql, |q - qh - ql| <= 2^-18 |q|):
+// v_dot2c_f32_bf16 multiplies two element pairs per instruction, so 8 elements cost 8 instructions
+// instead of 8 unpacks and 8 FMAs.  The products are exact in fp32; the accumulation error and the
+// 2^-18 of the query split are part of the bound the finalize step certifies with.
+typedef __bf16 bf16x2s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float dot2_bf16(uint32_t x, uint32_t q, float acc) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2s, x), __builtin_bit_cast(bf16x2s, q), acc, false);
+}
+__device__ __forceinline__ float dot_unit_pk(const u32x4& x, const uint32_t* qh, const uint32_t* ql, float acc) {
+    acc = dot2_bf16(x.x, qh[0], acc); acc = dot2_bf16(x.y, qh[1], acc);
+    acc = dot2_bf16(x.z, qh[2], acc); acc = dot2_bf16(x.w, qh[3], acc);
+    acc = dot2_bf16(x.x, ql[0], acc); acc = dot2_bf16(x.y, ql[1], acc);
+    acc = dot2_bf16(x.z, ql[2], acc); acc = dot2_bf16(x.w, ql[3], acc);
+    return acc;
+}
+__device__ __forceinline__ uint32_t bf16_bits(float f) { return (uint32_t)__builtin_bit_cast(unsigned short, (__bf16)f); }
+
 // fp32 all-reduce over groups of LPR consecutive lanes without the LDS crossbar: DPP quad
 // permutes and row mirrors inside 16-lane rows, permlane swaps across rows.  Every lane of a
 // group ends with the group's sum (the pairing differs from an xor butterfly, which is
@@ -240,15 +257,32 @@ scan_kernel(ScanParams p) {
     const int grp = lane / LPR;
     const float* q = p.q + (size_t)blockIdx.y * p.dpad;
 
+    constexpr bool PK = DT == VDB_BF16;            // packed bf16 arithmetic (see dot_unit_pk)
     int   off[NCH];
-    float qv[NCH][EPL];
+    float qv[NCH][PK ? 1 : EPL];
+    uint32_t qh[NCH][4], ql[NCH][4];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int unit = c * LPR + lir;
         const bool act = unit < p.m;
         off[c] = act ? unit * 16 : 0;
+        if constexpr (PK) {
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) qv[c][e] = act ? q[unit * EPL + e] : 0.f;
+            for (int e = 0; e < 4; ++e) {
+                uint32_t h[2], l[2];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const float x = act ? q[unit * 8 + 2 * e + b] : 0.f;
+                    h[b] = bf16_bits(x);
+                    l[b] = bf16_bits(x - __uint_as_float(h[b] << 16));
+                }
+                qh[c][e] = h[0] | (h[1] << 16);
+                ql[c][e] = l[0] | (l[1] << 16);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) qv[c][e] = act ? q[unit * EPL + e] : 0.f;
+        }
     }
 
     WaveSel sel;
@@ -279,7 +313,10 @@ scan_kernel(ScanParams p) {
         for (int u = 0; u < U; ++u) {
             float acc = 0.f;
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) acc = dot_unit<DT>(x[u][c], qv[c], acc);
+            for (int c = 0; c < NCH; ++c) {
+                if constexpr (PK) acc = dot_unit_pk(x[u][c], qh[c], ql[c], acc);
+                else acc = dot_unit<DT>(x[u][c], qv[c], acc);
+            }
             acc = group_sum<LPR>(acc);
             const long long r = base + u * RPI + grp;
             const float key = p.l2 ? (2.f * acc - nn[u]) : acc;
@@ -401,7 +438,14 @@ int scan_grid(const TableView& t, const SelGeom& g, int n_cu) {
     if (need < 1) need = 1;
     // LDS and the 1024-thread bound admit one 16-wave block per CU; smaller blocks pack more.
     long long cap = (long long)n_cu * (g.W >= 16 ? 1 : (16 / g.W));
-    if (g_tune.blocks_per_cu > 0) cap = (long long)n_cu * g_tune.blocks_per_cu;
+    if (g_tune.blocks_per_cu > 0) {
+        // Tables that stream in about a millisecond or less do best with only the blocks that are
+        // resident at once (two of 8 waves per CU): a second round of blocks costs its start-up and
+        // the first round's tail again (1 M x 768 fp32: 78.8 -> 83.2 % of the HBM peak); long scans
+        // gain more from the finer balance of four blocks per CU.
+        const double bytes = (double)t.n * t.m * 16.0;
+        cap = (long long)n_cu * (bytes < 8e9 && g_tune.blocks_per_cu > 2 ? 2 : g_tune.blocks_per_cu);
+    }
     return (int)(need < cap ? need : cap);
 }
 
@@ -435,7 +479,9 @@ hipError_t launch_scan(const TableView& t, const float* qprep, int64_t nq, int d
     ScanParams p;
     p.rows = t.rows; p.n2 = t.n2; p.q = qprep; p.n = t.n; p.m = t.m; p.dpad = dpad;
     p.K = g.K; p.C = g.C; p.l2 = (t.metric == VDB_METRIC_L2) ? 1 : 0;
-    p.contiguous = g_tune.contiguous;
+    // each wave scans one contiguous range of a long table; over short ones the waves advance through the
+    // table side by side, so that they all end together (1 M x 768 fp32: 83.3 -> 84.0 % of the HBM peak)
+    p.contiguous = g_tune.contiguous && (double)t.n * t.m * 16.0 >= 8e9;
     p.cand_s = cand_s; p.cand_t = cand_t; p.cand_h = cand_h; p.floor = floor;
     const ScanShape s = scan_shape(t.m, t.dt);
     const dim3 grid((unsigned)G, (unsigned)nq), block((unsigned)g.W * 64);
@@ -954,7 +1000,7 @@ hipError_t launch_finalize(const TableView& t, const float* qprep, const QInfo* 
                            int dpad, const SelGeom& g, int G, int k,
                            const float* cand_s, const long long* cand_t, const float* cand_h,
                            long long* out_ids, float* out_scores, int* out_counts,
-                           int* need_exact, long long* counters, hipStream_t st) {
+                           int* need_exact, long long* counters, const FlatBound& fb, hipStream_t st) {
     FinParams p;
     p.t = t; p.q = qprep; p.qinfo = qinfo; p.dpad = dpad;
     p.K = g.K; p.C = g.C; p.G = G; p.k = k;
@@ -962,7 +1008,7 @@ hipError_t launch_finalize(const TableView& t, const float* qprep, const QInfo* 
     p.out_ids = out_ids; p.out_scores = out_scores; p.out_counts = out_counts;
     p.need_exact = need_exact; p.counters = counters;
     p.flat_cnt = nullptr; p.flat_cap = 0; p.flat_tau = nullptr; p.flat_lost = nullptr; p.flat_bad = nullptr;
-    p.dd_mult = 1.0; p.extra_rel = 0.0; p.extra_abs = 0.0; p.l2_bias = 0.0; p.floor_out = nullptr;
+    p.dd_mult = fb.dd_mult; p.extra_rel = fb.extra_rel; p.extra_abs = fb.extra_abs; p.l2_bias = 0.0; p.floor_out = nullptr;
     int kr = 1; while (kr < g.K) kr <<= 1;
     const size_t lds = 1088 + (size_t)g.K * 12 + (size_t)kr * 12 + (size_t)FIN_CAP * 8;
     hipError_t e = allow_lds(finalize_kernel, lds);

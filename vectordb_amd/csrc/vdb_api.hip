@@ -281,6 +281,10 @@ static int search_scan_path(const TableView& tv, const SelGeom& g, int dpad, int
     // rows filling and sorting its own list.  A scan of a small sample of the rows (1/256) first
     // gives the K-th best key of the sample, a lower bound of the K-th best key of the table; the
     // full scan starts with it as a floor, so that only about 256*K rows in total pass the compare.
+    // bf16 rows are scanned against the query as packed bf16 hi + lo parts (two products per element,
+    // the split leaves 2^-18 of |q| unrepresented): both are part of the certificate's bound
+    FlatBound fb;
+    if (tv.dt == VDB_BF16) { fb.dd_mult = 2.0; fb.extra_rel = 4.0e-6; }
     const size_t rowbytes = (size_t)tv.m * 16;
     const bool sampled = g.K >= 64 && rowbytes <= 1024 && tv.n >= 262144 && G.tune_sample != 0;
     TableView tvs = tv;
@@ -331,7 +335,7 @@ static int search_scan_path(const TableView& tv, const SelGeom& g, int dpad, int
         }
         VDB_HIP(launch_finalize(tv, qprep, qinfo, nqi, dpad, g, Gx * g.W, k, cs, ct, (const float*)ws.cand_h.p,
                                 out_ids + (size_t)q0 * k, out_scores + (size_t)q0 * k, out_counts + q0,
-                                ne, G.d_counters, st));
+                                ne, G.d_counters, fb, st));
         VDB_HIP(launch_exact(tv, qprep, nqi, dpad, g, Gx, k, cs, ct,
                              out_ids + (size_t)q0 * k, out_scores + (size_t)q0 * k, out_counts + q0,
                              ne, G.d_counters, st));

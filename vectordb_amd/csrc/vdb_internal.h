@@ -66,22 +66,23 @@ hipError_t launch_scan(const TableView& t, const float* qprep, int64_t nq, int d
                        const SelGeom& g, int G, float* cand_s, long long* cand_t, float* cand_h,
                        const float* floor, hipStream_t st);
 
-// Merge candidates, re-score them canonically (fp64), order by (score, id), certify.
-hipError_t launch_finalize(const TableView& t, const float* qprep, const QInfo* qinfo, int64_t nq,
-                           int dpad, const SelGeom& g, int G, int k,
-                           const float* cand_s, const long long* cand_t, const float* cand_h,
-                           long long* out_ids, float* out_scores, int* out_counts,
-                           int* need_exact, long long* counters, hipStream_t st);
-
-// Same for the batched path: one unsorted candidate array of `cap` slots per query, `cnt[q]`
-// appended, every non-candidate row known to have a fast key <= tau[q].
-// Terms the batched path adds to the fp32 scoring-error bound of the certificate.
+// Terms a fast pass adds to the plain fp32 scoring-error bound of the certificate.
 struct FlatBound {
     double l2_bias = 0.0;     // 1 when L2 keys are accumulated on top of the row norm (partial sums of that size)
     double dd_mult = 1.0;     // accumulation chain length in units of d (2 when hi and lo parts are summed)
     double extra_rel = 0.0;   // relative error of the query as the MFMA sees it (x ||x|| ||q||)
     double extra_abs = 0.0;   // absolute error per unit of ||x|| (fp16 subnormal spacing)
 };
+
+// Merge candidates, re-score them canonically (fp64), order by (score, id), certify.
+hipError_t launch_finalize(const TableView& t, const float* qprep, const QInfo* qinfo, int64_t nq,
+                           int dpad, const SelGeom& g, int G, int k,
+                           const float* cand_s, const long long* cand_t, const float* cand_h,
+                           long long* out_ids, float* out_scores, int* out_counts,
+                           int* need_exact, long long* counters, const FlatBound& fb, hipStream_t st);
+
+// Same for the batched path: one unsorted candidate array of `cap` slots per query, `cnt[q]`
+// appended, every non-candidate row known to have a fast key <= tau[q].
 hipError_t launch_lists_floor(const SelGeom& g, int G, int64_t nq, const float* cand_s, const long long* cand_t,
                               const float* cand_h, float* floor_out, hipStream_t st);
 hipError_t launch_finalize_flat(const TableView& t, const float* qprep, const QInfo* qinfo, int64_t nq,
