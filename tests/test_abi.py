@@ -129,3 +129,19 @@ def test_cluster_client_reports_a_missing_gpu_as_a_status():
     assert not c.create_table({"table_name": "a", "dimension": 4}).OK()
     st, res = c.search_vectors(table_name="a", query_records=[[0.0] * 4], top_k=3)
     assert not st.OK() and res == []
+
+
+def test_call_merger_under_thread_sanitizer(tmp_path):
+    """The turn-taking that merges concurrent blocking vdb_search calls (vectordb_amd/csrc/host_merge.h)
+    is plain host code: a CPU build of exactly that header runs 64 threads over three keys under
+    ThreadSanitizer with a stand-in search (tests/native/merge_tsan.cpp)."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no host compiler")
+    exe = str(tmp_path / "merge_tsan")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-pthread",
+                           os.path.join(ROOT, "tests", "native", "merge_tsan.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "ThreadSanitizer" not in out.stderr and "wrong 0" in out.stdout

@@ -674,3 +674,62 @@ def test_full_size_properties(engine, table_name, metric, dtype, n, d, k, nq):
         ssc = OC.scores(O.prepare_store(OC.synth_rows(0, s0, 100_000, d), m, dt), qp, m)
         better = np.nonzero(ssc < sc[j, k - 1] if metric == "l2" else ssc > sc[j, k - 1])[0] + s0
         assert set(better.tolist()) <= set(ids[j].tolist())
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
+def test_rows_that_are_not_finite_are_refused(engine, table_name, dtype):
+    """A NaN, an infinity or a value beyond the storage type's range makes the whole insert fail with
+    VDB_EINVAL: nothing of the call becomes visible, the table's norm bound stays finite and later
+    searches answer from the fast path as before."""
+    from vectordb_amd._lib import VdbError
+    d, n, k = 64, 5000, 10
+    rows = cases.make_rows("synth", 77, n, d)
+    ids = np.arange(n, dtype=np.int64)
+    stored = _load(engine, table_name, rows, ids, O.IP, cases.DTYPES[dtype])
+    before = engine.stats()
+    for bad_value in (np.nan, np.inf, -np.inf) + ((1.0e6,) if dtype == "f16" else ()):
+        bad = cases.make_rows("synth", 78, 7, d)
+        bad[3, 11] = bad_value
+        with pytest.raises(VdbError) as ei:
+            engine.insert(table_name, bad, np.arange(n, n + 7, dtype=np.int64))
+        assert ei.value.code == _lib.EINVAL and "finite" in ei.value.message
+        assert engine.count(table_name) == n
+    # a good insert after the refused ones lands where they would have
+    more = cases.make_rows("synth", 79, 3, d)
+    engine.insert(table_name, more, np.arange(n, n + 3, dtype=np.int64))
+    assert engine.count(table_name) == n + 3
+    stored2 = np.concatenate([stored, O.prepare_store(more, O.IP, cases.DTYPES[dtype])])
+    q = cases.make_queries("synth", 80, 4, d, rows)
+    _check(engine, table_name, stored2, np.arange(n + 3, dtype=np.int64), q, k, O.IP)
+    after = engine.stats()
+    assert after[1] == before[1], "queries fell back to the exact pass: the norm bound was spoiled"
+
+
+def test_table_grows_in_place_past_half_of_the_hbm(engine, table_name):
+    """No reserve call: eight appends grow a bf16 table to 55 % of the GPU's memory.  Growth by
+    allocate-and-copy would need old and new arrays side by side (more than the GPU holds); the table
+    grows inside its reserved address range instead, and rows stored by the first append stay where
+    they are and stay searchable after every later one."""
+    import torch
+    _, total = torch.cuda.mem_get_info()
+    d, k = 1024, 10
+    rows_target = int(0.55 * total / (d * 2 + 12))
+    chunk = rows_target // 8
+    engine.create_table(table_name, d, _lib.METRIC_IP, _lib.BF16)
+    probe = None
+    for i in range(8):
+        engine.insert_synthetic(table_name, chunk, seed=91, first_row=i * chunk)
+        info = engine.table_info(table_name)
+        assert info["rows"] == (i + 1) * chunk and info["capacity"] >= info["rows"]
+        if probe is None:
+            probe, pid = engine.fetch_rows(table_name, 4321, 1)
+            assert int(pid[0]) == 4321
+        again, _ = engine.fetch_rows(table_name, 4321, 1)
+        assert np.array_equal(again.view(np.uint32), probe.view(np.uint32))
+        ids, scores, cnt = engine.search(table_name, probe * 4.0, k)
+        assert int(cnt[0]) == k
+        # the row itself scores ||x||^2 * 4; any row that beats it must really score higher
+        own = float((probe[0].astype(np.float64) ** 2).sum() * 4.0)
+        assert 4321 in ids[0].tolist() or float(scores[0, -1]) >= np.float32(own)
+        assert np.all(np.diff(scores[0]) <= 0)
+    assert (engine.table_info(table_name)["rows"] * (d * 2)) > 0.5 * total

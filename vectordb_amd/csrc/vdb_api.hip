@@ -1,6 +1,7 @@
 // C-ABI layer: table registry, HBM-resident store with device-side append, search orchestration.
 // See include/vdb.h for the contract of every entry point.
 #include "vdb_internal.h"
+#include "host_merge.h"
 
 #include <atomic>
 #include <cmath>
@@ -128,11 +129,7 @@ struct Global {
     hipEvent_t chain_ev[16] = {};
     int chain_head = -1;
     hipStream_t chain_last = nullptr;
-    // merging of concurrent blocking host searches (guarded by co_mu; see vdb_search)
-    std::mutex co_mu;
-    std::condition_variable co_cv;
-    bool co_busy = false;
-    std::vector<HostReq*> co_pending;
+    // merging of concurrent blocking host searches (see vdb_search and host_merge.h)
     int coalesce_host = 1;
 };
 static Global G;
@@ -1262,6 +1259,9 @@ int vdb_search_dev_noalloc(const char* name, int64_t nq, const float* queries_de
 namespace vdb {
 // One blocking host call, possibly carrying the queries of several callers (see vdb_search).
 struct HostReq {
+    MergeKey       key;                  // (table, k): what may share one batched search
+    int64_t        weight = 0;           // = nq
+    bool           done = false;         // guarded by the merger
     std::shared_ptr<Table> t;
     int            k = 0;
     int64_t        nq = 0;
@@ -1271,7 +1271,6 @@ struct HostReq {
     int32_t*       out_counts = nullptr;
     int            rc = VDB_OK;
     std::string    err;
-    bool           done = false;
 };
 
 // Runs the requests of `batch` (same table, same k) as one search.  The result code and message
@@ -1384,28 +1383,11 @@ int vdb_search(const char* name, int64_t nq, const float* queries, int k,
         search_host_batch(batch);
         return req.rc;
     }
-    {
-        std::unique_lock<std::mutex> lk(G.co_mu);
-        G.co_pending.push_back(&req);
-        G.co_cv.wait(lk, [&] { return req.done || !G.co_busy; });
-        if (req.done) return req.rc == VDB_OK ? VDB_OK : fail(req.rc, req.err);
-        G.co_busy = true;                         // this caller's turn
-        int64_t total = 0;
-        std::vector<HostReq*> rest;
-        for (HostReq* r : G.co_pending) {
-            if (r->t.get() == req.t.get() && r->k == k && (r == &req || total + r->nq <= 1024)) { batch.push_back(r); total += r->nq; }
-            else rest.push_back(r);
-        }
-        G.co_pending.swap(rest);
-    }
-    search_host_batch(batch);
-    {
-        std::lock_guard<std::mutex> lk(G.co_mu);
-        for (HostReq* r : batch) if (r != &req) r->done = true;
-        G.co_busy = false;
-    }
-    G.co_cv.notify_all();
-    return req.rc;
+    req.key = MergeKey(req.t.get(), k);
+    req.weight = nq;
+    static CallMerger<HostReq> merger;       // calls with different (table, k) never wait for each other
+    merger.submit(req, 1024, [](std::vector<HostReq*>& b) { search_host_batch(b); });
+    return req.rc == VDB_OK ? VDB_OK : fail(req.rc, req.err);
 }
 
 int vdb_merge_topk_dev(int nparts, int64_t nq, int k, int metric, const int64_t* in_ids_dev,
