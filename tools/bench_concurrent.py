@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--threads", default="1,4,16,64")
     ap.add_argument("--seconds", type=float, default=3.0)
+    ap.add_argument("--inserters", type=int, default=0,
+                    help="threads that insert one row per call (as PUT /insert does) while the lookups run")
     args = ap.parse_args()
     m = Milvus()
     assert m.connect().OK()
@@ -40,6 +42,18 @@ def main():
         for nt in [int(x) for x in args.threads.split(",")]:
             stop = time.perf_counter() + args.seconds
             counts = [0] * nt
+            inserted = [0] * max(1, args.inserters)
+            rng = np.random.default_rng(5)
+            new_rows = rng.standard_normal((4096, args.dim)).astype(np.float32).tolist()
+
+            def inserter(t):
+                i = 0
+                base = 1 << 40
+                while time.perf_counter() < stop:
+                    st, _ = m.insert(name, records=[new_rows[i % 4096]], ids=[base + t * (1 << 30) + inserted[t]])
+                    assert st.OK(), st.message
+                    inserted[t] += 1
+                    i += 1
 
             def worker(t):
                 i = t
@@ -51,12 +65,15 @@ def main():
 
             t0 = time.perf_counter()
             threads = [threading.Thread(target=worker, args=(t,)) for t in range(nt)]
+            threads += [threading.Thread(target=inserter, args=(t,)) for t in range(args.inserters)]
             for th in threads:
                 th.start()
             for th in threads:
                 th.join()
             dt = time.perf_counter() - t0
-            print("merged=%d threads=%3d: %8.1f QPS  (%d queries, %.2f s)" % (merged, nt, sum(counts) / dt, sum(counts), dt), flush=True)
+            print("merged=%d threads=%3d inserters=%d: %8.1f QPS  (%d queries, %.2f s)%s" % (
+                merged, nt, args.inserters, sum(counts) / dt, sum(counts), dt,
+                "  %.1f inserts/s" % (sum(inserted) / dt) if args.inserters else ""), flush=True)
     eng.set_option("coalesce_host", 1)
     eng.drop_table(name)
 

@@ -729,7 +729,13 @@ int vdb_init(int device) {
     G.n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     e = hipMalloc((void**)&G.d_counters, 32 * sizeof(long long));
     if (e == hipSuccess) e = hipMemset(G.d_counters, 0, 32 * sizeof(long long));
-    if (e == hipSuccess) e = hipStreamCreate(&G.insert_stream);
+    if (e == hipSuccess) {
+        // appends are tiny next to a table scan: a high-priority stream lets them run between the
+        // workgroups of the scans that are queued, instead of behind all of them
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); hi = 0; }
+        e = hipStreamCreateWithPriority(&G.insert_stream, hipStreamDefault, hi);
+    }
     if (e != hipSuccess) return fail(VDB_ENOGPU, std::string("device set-up: ") + hipGetErrorString(e));
     G.device = device;
     if (device < NOALLOC_MAX_DEV && !g_noalloc_ptr[device]) {
