@@ -9,8 +9,8 @@ A step = one query (or one batch of --nq queries) scored against every stored ro
 returned (ids + scores) in device memory.  With N > 1 the rows are row-sharded over the N ranks
 (strong scaling): each rank scans its shard, one RCCL all-gather exchanges the per-rank top-k
 records, every rank merges them.  Inputs (table and queries) are resident in HBM before the timed
-region.  Single-query steps are issued round-robin on --streams HIP streams (default 3), as the
-requests of concurrent clients are: the library runs the table scans strictly one after the other,
+region.  Single-query steps are issued round-robin on --streams HIP streams (default: 3; 2 over a
+single-GPU table under 8 GB), as the requests of concurrent clients are: the library runs the table scans strictly one after the other,
 and the short kernels and the collective around one scan overlap with the next query's scan.
 
 Prints ONE JSON line (rank 0): the throughput, the roofline of the dominant kernel (single queries:
@@ -118,7 +118,7 @@ def main() -> None:
     ap.add_argument("--nq", type=int, default=1, help="queries per step")
     ap.add_argument("--metric", default="cosine", choices=["cosine", "ip", "l2"])
     ap.add_argument("--dtype", default="f32", choices=["bf16", "f16", "f32"])
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--streams", type=int, default=0,
                     help="queries in flight: step i runs on HIP stream i %% streams, as the requests of "
                          "concurrent clients do; the library runs the table scans one after the other and "
                          "overlaps the short kernels and the collective around them")
@@ -193,6 +193,10 @@ def rank_main(args, world: int) -> None:
         eng.synth_fill_dev(queries.data_ptr(), total * nq, dim, seed=1, first_row=0, stream=stream.cuda_stream)
         local_search, merge = gpu_backend(eng, table, nq, k, metric)
         # batches keep the GPU busy on their own; single queries are pipelined over several streams
+        if n_streams <= 0:
+            # queries in flight: three over a long scan; two over a scan of a few hundred microseconds, where
+            # a third queue's small kernels cost more between scans than they hide (measured: 12 us per query)
+            n_streams = 3 if (n_local * dim * esz >= 8e9 or world > 1) else 2
         n_streams = max(1, n_streams) if nq == 1 else 1
         searchers = [ShardedSearcher(nq, k, dev, local_search, merge) for _ in range(n_streams)]
         streams = [stream] if n_streams == 1 else [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
@@ -356,8 +360,8 @@ def rank_main(args, world: int) -> None:
         secondary.append(run_workload(table, args.rows, n_local, 768, "f32", "cosine", 10, 1024, 6, 2, 1, latency=False))
         eng.drop_table(table)
         for (rows, dim, dtype, mname, k, nq, steps, warmup, note) in (
-                (1_000_000, 768, "f32", "cosine", 10, 1, 200, 20, "1M x 768 fp32 single query"),
-                (12_500_000, 128, "bf16", "ip", 100, 1, 200, 20, "one shard of 8 of the 100M x 128 bf16 top-100 configuration"),
+                (1_000_000, 768, "f32", "cosine", 10, 1, 1000, 100, "1M x 768 fp32 single query"),
+                (12_500_000, 128, "bf16", "ip", 100, 1, 1000, 100, "one shard of 8 of the 100M x 128 bf16 top-100 configuration"),
                 (20_000_000, 768, "f16", "l2", 10, 256, 6, 2, "20M of the 125M rows one GPU holds in the 1B x 768 fp16 L2 batch-256 configuration")):
             name = "bench_%s_%d" % (dtype, rows)
             eng.create_table(name, dim, METRICS[mname], DTYPES[dtype][0])
