@@ -630,6 +630,36 @@ def test_batched_fp32_with_large_magnitudes_and_ties(engine, table_name, split):
         engine.set_option("gemm32_split", 2)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("nq", [3, 40, 150])
+def test_l2_rows_with_heavy_tailed_norms_stay_on_the_fast_path(engine, table_name, nq, dtype):
+    """L2 keys carry the error term of their own row, so one row in a hundred that is a hundred times
+    longer than the rest does not send queries to the exact pass (with the table-wide norm bound it
+    sends every batched query there); same exact results either way.  3 queries: scan; 40: the
+    128-query tile kernel; 150: the ping-pong kernel."""
+    n, d = 70_000, 96
+    rows = cases.make_rows("synth", 67, n, d)
+    rows[::100] *= 100.0
+    ids = cases.make_ids("hash", 67, n)
+    q = cases.make_queries("synth", 67, nq, d, rows)
+    dt = {"f32": _lib.F32, "bf16": _lib.BF16, "f16": _lib.F16}[dtype]
+    stored = _load(engine, table_name, rows, ids, O.L2, dt)
+    try:
+        fallbacks = {}
+        for rb in (1, 0):
+            engine.set_option("l2_row_bounds", rb)
+            before = engine.stats()
+            _check(engine, table_name, stored, ids, q, 10, O.L2)
+            after = engine.stats()
+            fallbacks[rb] = after[1] - before[1]
+        assert fallbacks[1] == 0, fallbacks
+        print("exact passes with / without the per-row term:", fallbacks[1], fallbacks[0])
+        if nq == 150 and dtype == "f32":
+            assert fallbacks[0] > 0, fallbacks       # the case the per-row term exists for
+    finally:
+        engine.set_option("l2_row_bounds", 1)
+
+
 @pytest.mark.parametrize("metric,dtype,n,d,k,nq", [
     ("cosine", "f32", 10_000_000, 768, 10, 4),        # headline / BASELINE config 2 shape at 10M
     ("cosine", "f32", 10_000_000, 768, 10, 1024),     # config 3: batch 1024

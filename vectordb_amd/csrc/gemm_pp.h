@@ -28,6 +28,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "vdb_internal.h"
 
 namespace vdb {
 
@@ -40,6 +41,7 @@ typedef unsigned int pp_u32x4 __attribute__((ext_vector_type(4)));
 struct GemmPPParams {
     const unsigned short* X;     // row-major rows [n][ldx], or (TILED) the tiled image: see pp_tiled_index
     const float* n2;             // [n] squared row norms (L2 only)
+    RowBound     rb;             // L2: error term folded into the accumulators' start values
     const unsigned short* Q;     // tiled image of the queries: [ceil(nq/256)][nks] blocks of 256 x 32
     const float* thr;            // [nq] a candidate must have key > thr
     long long    n;
@@ -147,6 +149,14 @@ gemm_pp_kernel(GemmPPParams p) {
         const int q = qt * PP_TN + wn * 64 + ni * MB + li;
         const float t = (q < p.nq) ? p.thr[q] : __builtin_huge_valf();
         thr[ni] = L2M ? -t : t;                    // L2: candidates have acc < -thr
+    }
+    // L2: the rows' error term (see RowBound); two wave-uniform values, fetched before the loop as well
+    bool rbon = false;
+    float ea = 0.f, es = 0.f;
+    if constexpr (L2M) {
+        rbon = p.rb.qinfo != nullptr;
+        if (rbon) { ea = p.rb.a; es = rowbound_s(p.rb, lane); }
+        asm volatile("" : "+v"(ea), "+v"(es));
     }
     // the thresholds are waited for here, ahead of every global_load_lds: a wait at their first use
     // inside the loop would have to be vmcnt(0) and drain the prefetch once per tile
@@ -342,7 +352,11 @@ gemm_pp_kernel(GemmPPParams p) {
                 for (int mi = 0; mi < NMI; ++mi)
 #pragma unroll
                     for (int j = 0; j < AR / 4; ++j) {
-                        const pp_f32x4 v = *(const pp_f32x4*)(nb + (mi * MB + 8 * j) * 4);
+                        pp_f32x4 v = *(const pp_f32x4*)(nb + (mi * MB + 8 * j) * 4);
+                        if (rbon) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = rowbound_adj(v[e], ea, es);
+                        }
 #pragma unroll
                         for (int ni = 0; ni < NNI; ++ni)
 #pragma unroll

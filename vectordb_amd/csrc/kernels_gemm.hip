@@ -45,6 +45,7 @@ struct GemmParams {
     int*         cnt;        // [nq]
     int*         lost;       // [nq] set when a candidate could not be stored
     int          cap;
+    RowBound     rb;         // L2: error term added to every key
 };
 
 __device__ __forceinline__ f32x4 ldg4(const float* p) { return *(const f32x4*)p; }
@@ -64,6 +65,9 @@ gemm_thresh_kernel(GemmParams p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
     const int qt = blockIdx.y;
+    const bool rbon = p.l2 && p.rb.qinfo != nullptr;
+    const float ea = rbon ? p.rb.a : 0.f;
+    const float es = rbon ? rowbound_s(p.rb, lane) : 0.f;
     const int nks = (p.dpad + GB_K - 1) / GB_K;
     const int d4 = p.dpad >> 2;                    // float4 units per query row (= per stored row)
 
@@ -153,6 +157,12 @@ gemm_thresh_kernel(GemmParams p) {
                     const long long row = row0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     rn2[mi][r] = p.n2[row < p.n ? row : p.n - 1];
                 }
+            if (rbon) {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rn2[mi][r] = rowbound_adj(rn2[mi][r], ea, es);
+            }
         }
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
@@ -183,7 +193,7 @@ hipError_t launch_gemm_thresh(const TableView& t, const float* qprep, int nq, in
                               int n_cu, hipStream_t st) {
     if (ntiles <= 0) return hipSuccess;
     GemmParams p;
-    p.X = (const float*)t.rows; p.n2 = t.n2; p.Q = qprep; p.thr = thr; p.n = t.n; p.nq = nq;
+    p.X = (const float*)t.rows; p.n2 = t.n2; p.rb = t.rb; p.Q = qprep; p.thr = thr; p.n = t.n; p.nq = nq;
     p.dpad = dpad; p.ldx = t.m * 4; p.l2 = t.metric == VDB_METRIC_L2 ? 1 : 0;
     p.tile0 = tile0; p.tile_stride = tile_stride; p.ntiles = ntiles;
     p.cand_s = cand_s; p.cand_t = cand_t; p.cnt = cnt; p.lost = lost; p.cap = cap;
@@ -319,6 +329,7 @@ struct Gemm16Params {
     int*         cnt;
     int*         lost;
     int          cap;
+    RowBound     rb;
 };
 
 template <int DT>
@@ -340,6 +351,9 @@ gemm16_dense_kernel(Gemm16Params p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
     const int qt = blockIdx.y;
+    const bool rbon = p.l2 && p.rb.qinfo != nullptr;
+    const float ea = rbon ? p.rb.a : 0.f;
+    const float es = rbon ? rowbound_s(p.rb, lane) : 0.f;
     const int nks = (p.dpad + HB_K - 1) / HB_K;
     const int d8 = p.dpad >> 3;                    // 16-byte units per row
 
@@ -453,6 +467,10 @@ gemm16_dense_kernel(Gemm16Params p) {
                             const int o = lr0 + (r & 3) + 8 * (r >> 2);
                             rn2[r] = n2p[o < nloc ? o : 0];
                         }
+                        if (rbon) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) rn2[r] = rowbound_adj(rn2[r], ea, es);
+                        }
                     }
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni) {
@@ -510,6 +528,7 @@ struct Gemm32sParams {
     int*         cnt;
     int*         lost;
     int          cap;
+    RowBound     rb;
 };
 
 // 4 fp32 -> 4 bf16 hi (packed in 8 bytes) and 4 bf16 lo
@@ -577,6 +596,9 @@ gemm32s_kernel(Gemm32sParams p) {
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
     const int qt = blockIdx.y;
+    const bool rbon = p.l2 && p.rb.qinfo != nullptr;
+    const float ea = rbon ? p.rb.a : 0.f;
+    const float es = rbon ? rowbound_s(p.rb, lane) : 0.f;
     const int nks = (p.dpad + KS - 1) / KS;
     const int dch = p.dpad / EPC;                  // 16-byte chunks per row
 
@@ -762,6 +784,10 @@ gemm32s_kernel(Gemm32sParams p) {
                             const int o = lr0 + (r & 3) + 8 * (r >> 2);
                             rn2[r] = n2p[o < nloc ? o : 0];
                         }
+                        if (rbon) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) rn2[r] = rowbound_adj(rn2[r], ea, es);
+                        }
                     }
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni) {
@@ -840,7 +866,7 @@ hipError_t launch_gemm32s(const TableView& t, const unsigned short* qhi, const u
                           float* cand_s, long long* cand_t,
                           int* cnt, int* lost, int cap, int n_cu, hipStream_t st) {
     Gemm32sParams p;
-    p.X = t.rows; p.n2 = t.n2; p.Qhi = qhi; p.Qlo = qlo; p.thr = thr; p.n = t.n; p.nq = nq;
+    p.X = t.rows; p.n2 = t.n2; p.rb = t.rb; p.Qhi = qhi; p.Qlo = qlo; p.thr = thr; p.n = t.n; p.nq = nq;
     p.dpad = dpad; p.qstride = qstride; p.ldx = t.dt == VDB_F32 ? t.m * 4 : t.m * 8; p.l2 = t.metric == VDB_METRIC_L2 ? 1 : 0;
     p.tile_stride = tile_stride < 1 ? 1 : tile_stride;
     p.ntiles = 0;                                    // set by the launcher of the chosen tile shape
@@ -862,7 +888,7 @@ hipError_t launch_gemm16_thresh(const TableView& t, const unsigned short* qhi, c
     if (!dense)
         return launch_gemm32s(t, qhi, qlo, qstride, split, nq, dpad, thr, tile_stride, cand_s, cand_t, cnt, lost, cap, n_cu, st);
     Gemm16Params p;
-    p.X = (const unsigned short*)t.rows; p.n2 = t.n2; p.Qhi = qhi; p.Qlo = qlo; p.thr = thr; p.n = t.n; p.nq = nq;
+    p.X = (const unsigned short*)t.rows; p.n2 = t.n2; p.rb = t.rb; p.Qhi = qhi; p.Qlo = qlo; p.thr = thr; p.n = t.n; p.nq = nq;
     p.dpad = dpad; p.ldq = qstride; p.ldx = t.m * 8; p.l2 = t.metric == VDB_METRIC_L2 ? 1 : 0;
     p.tile0 = 0; p.tile_stride = tile_stride; p.ntiles = ntiles;
     p.cand_s = cand_s; p.cand_t = cand_t; p.cnt = cnt; p.lost = lost; p.cap = cap;
@@ -996,7 +1022,7 @@ hipError_t launch_gemm_pp(const TableView& t, const unsigned short* qimage, int 
                           long long tile_stride, float* cand_s, long long* cand_t, int* cnt, int* lost, int cap,
                           int n_cu, hipStream_t st) {
     GemmPPParams p;
-    p.X = t.rows16; p.n2 = t.n2; p.Q = qimage; p.thr = thr; p.n = t.n; p.ldx = t.ld16; p.nq = nq;
+    p.X = t.rows16; p.n2 = t.n2; p.rb = t.rb; p.Q = qimage; p.thr = thr; p.n = t.n; p.ldx = t.ld16; p.nq = nq;
     p.qstride = 0; p.nks = pp_nks(dpad);
     p.tile_stride = tile_stride < 1 ? 1 : tile_stride;
     p.ntiles = ((t.n + PP_TM - 1) / PP_TM + p.tile_stride - 1) / p.tile_stride;

@@ -220,6 +220,7 @@ struct ScanParams {
     long long*   cand_t;
     float*       cand_h;    // [nq][G*W]: best key of each list, contiguous for the finalize kernel
     const float* floor;     // [nq] lower bound of the K-th best key per query, or null
+    RowBound     rb;        // L2: error term added to every key (see RowBound)
 };
 
 // Launch tunables of the scan (set through vdb_set_option, defaults chosen by measurement).
@@ -288,6 +289,9 @@ scan_kernel(ScanParams p) {
     WaveSel sel;
     sel.init(S_all + (size_t)wave * p.C, T_all + (size_t)wave * p.C, p.C, p.K, lane,
              p.floor ? p.floor[blockIdx.y] : neg_inf());
+    const bool rbon = p.l2 && p.rb.qinfo != nullptr;
+    const float ea = rbon ? p.rb.a : 0.f;
+    const float es = rbon ? rowbound_s(p.rb, lane) : 0.f;
 
     const long long TW = (long long)gridDim.x * W;
     const long long gw = (long long)blockIdx.x * W + wave;
@@ -319,7 +323,7 @@ scan_kernel(ScanParams p) {
             }
             acc = group_sum<LPR>(acc);
             const long long r = base + u * RPI + grp;
-            const float key = p.l2 ? (2.f * acc - nn[u]) : acc;
+            const float key = p.l2 ? (2.f * acc - (rbon ? rowbound_adj(nn[u], ea, es) : nn[u])) : acc;
             const bool pass = (r <= last) && (lir == 0) && better(key, r, sel.thr_s, sel.thr_t);
             sel.push(pass, key, r, lane);
         }
@@ -357,6 +361,9 @@ scan_kernel_generic(ScanParams p) {
     WaveSel sel;
     sel.init(S_all + (size_t)wave * p.C, T_all + (size_t)wave * p.C, p.C, p.K, lane,
              p.floor ? p.floor[blockIdx.y] : neg_inf());
+    const bool rbon = p.l2 && p.rb.qinfo != nullptr;
+    const float ea = rbon ? p.rb.a : 0.f;
+    const float es = rbon ? rowbound_s(p.rb, lane) : 0.f;
 
     const long long TW = (long long)gridDim.x * W;
     const long long gw = (long long)blockIdx.x * W + wave;
@@ -393,7 +400,8 @@ scan_kernel_generic(ScanParams p) {
             a = group_sum<64>(a);
             const long long r = base + u;
             const long long rc = r < last ? r : last;
-            const float key = p.l2 ? (2.f * a - p.n2[rc]) : a;
+            float key = a;
+            if (p.l2) { const float nn = p.n2[rc]; key = 2.f * a - (rbon ? rowbound_adj(nn, ea, es) : nn); }
             const bool pass = (r <= last) && (lane == 0) && better(key, r, sel.thr_s, sel.thr_t);
             sel.push(pass, key, r, lane);
         }
@@ -479,6 +487,7 @@ hipError_t launch_scan(const TableView& t, const float* qprep, int64_t nq, int d
     ScanParams p;
     p.rows = t.rows; p.n2 = t.n2; p.q = qprep; p.n = t.n; p.m = t.m; p.dpad = dpad;
     p.K = g.K; p.C = g.C; p.l2 = (t.metric == VDB_METRIC_L2) ? 1 : 0;
+    p.rb = t.rb;
     // each wave scans one contiguous range of a long table; over short ones the waves advance through the
     // table side by side, so that they all end together (1 M x 768 fp32: 83.3 -> 84.0 % of the HBM peak)
     p.contiguous = g_tune.contiguous && (double)t.n * t.m * 16.0 >= 8e9;
@@ -545,6 +554,7 @@ struct FinParams {
     const int*       flat_lost;  // [nq]
     const int*       flat_bad;   // [nq] query not representable on the batched path (may be null)
     double           dd_mult, extra_rel, extra_abs, l2_bias;   // see FlatBound
+    int              force_exact;
     float*           floor_out;  // lists mode, non-null: only write the K-th best fast key per query and return
 };
 
@@ -871,13 +881,16 @@ finalize_kernel(FinParams p) {
                     const double eps = 1.05 * dd * u * bx * bq + xq + 4.0 * u * fabs(theta) + 1e-37;
                     cert = (double)RS[cnt - 1] > theta + eps;
                 } else {
-                    const double eps = 1.05 * u * (2.0 * dd * bx * bq + 4.0 * (bx * bx + 2.0 * bx * bq)) + 2.0 * xq
+                    // keys that carry their own row's error term bound the canonical keys by themselves
+                    const double eps = (p.t.rb.qinfo ? 4.0 * u * p.qinfo[qi].n2
+                                                     : 1.05 * u * (2.0 * dd * bx * bq + 4.0 * (bx * bx + 2.0 * bx * bq)) + 2.0 * xq)
                                        + 4.0 * u * fabs(theta) + 1e-37;
                     const double dist_k = -(double)RS[cnt - 1];
                     const double bound = p.qinfo[qi].n2 - theta - eps;     // outside rows are farther than this
                     cert = dist_k * (1.0 + 8.0 * u) + 1e-37 < bound;
                 }
             }
+            if (p.force_exact) cert = false;
             if (!cert) { const int pos = atomicAdd(&p.need_exact[0], 1); p.need_exact[1 + pos] = qi; }
             STAMP(5);
             atomicAdd((unsigned long long*)&p.counters[0], 1ull);
@@ -918,15 +931,42 @@ finalize_band_kernel(FinParams p) {
     __syncthreads();
 
     // every decision below is block-uniform
-    bool ok = p.flat_lost[qi] == 0 && (p.flat_bad == nullptr || p.flat_bad[qi] == 0) && M > p.k;
+    bool ok = p.flat_lost[qi] == 0 && (p.flat_bad == nullptr || p.flat_bad[qi] == 0) && M > p.k && !p.force_exact;
     uint32_t thr = 0;
     int need = 0;
-    if (ok) {
+    const bool rowb = l2 && p.t.rb.qinfo != nullptr;
+    double band = 0.0;
+    if (ok && rowb) {
+        // Keys with their row's error term e(x) added: a key u bounds its canonical key c from above
+        // (c <= u + D) and u - 2 e(x) - D bounds it from below, D = 4 u ||q||^2 for the shift by the
+        // query's norm.  The k-th largest lower bound L is a lower bound of the k-th best canonical
+        // key, and every row that can reach it has a key >= L - D.
+        const double u = 5.9604644775390625e-08;        // 2^-24
+        const double ea = (double)p.t.rb.a, es = (double)rowbound_s(p.t.rb, lane);
+        const double bq = (double)p.qinfo[qi].bq;
+        const double D = 4.0 * u * bq * bq;
+        auto lower = [&](long long i, int) -> float {
+            const float key = gs[i];
+            if (!(key > neg_inf())) return neg_inf();
+            const double n2 = (double)p.t.n2[gt[i]];
+            const double e = (ea * n2 + es * sqrt(n2)) * (1.0 + 1e-6) + 4.0 * u * n2;      // what the pass added, at most
+            const double lo = (double)key - 2.0 * e - D - 4.0 * u * fabs((double)key) - 1e-37;
+            float f = (float)lo;
+            if ((double)f > lo) f = nextafterf(f, neg_inf());                                   // round down
+            return f;
+        };
+        const bool all = select_kth(lower, M, p.k, hist, ctl, thr, need);
+        if (all) ok = false;
+        if (ok) {
+            const double L = (double)fkey_inv(thr);
+            band = L - D - 4.0 * u * fabs(L) - 1e-37;
+            if (!(band > (double)p.flat_tau[qi])) ok = false;
+        }
+    } else if (ok) {
         const bool all = select_kth([&](long long i, int) { return gs[i]; }, M, p.k, hist, ctl, thr, need);
         if (all) ok = false;                            // fewer than k usable keys
     }
-    double band = 0.0;
-    if (ok) {
+    if (ok && !rowb) {
         const double fk = (double)fkey_inv(thr);
         const double bx = sqrt((double)(*p.t.max_n2)) * (1.0 + 1e-6);
         const double bq = (double)p.qinfo[qi].bq;
@@ -996,6 +1036,21 @@ finalize_band_kernel(FinParams p) {
     }
 }
 
+RowBound l2_row_bound(const FlatBound& fb, int d, const QInfo* qinfo, int nq) {
+    // the terms of the table-wide bounds of the finalize kernels, sorted by their power of ||x||
+    const double u = 5.9604644775390625e-08;            // 2^-24
+    const double dd = (double)d * fb.dd_mult + 16.0;
+    const double a = u * (8.2 + 1.05 * dd * fb.l2_bias);
+    const double brel = u * (1.05 * (2.0 * dd + 8.0) + 8.0) + 2.0 * fb.extra_rel;
+    const double cabs = 2.0 * fb.extra_abs;
+    auto up = [](double v) { float f = (float)(v * 1.0001); if ((double)f < v) f = nextafterf(f, __builtin_huge_valf()); return f; };
+    RowBound rb;
+    rb.qinfo = qinfo; rb.nq = nq;
+    rb.a = up(a + 4.0 * u);                              // + the roundings of ||x||^2 - e(x) in fp32
+    rb.brel = up(brel); rb.cabs = up(cabs);
+    return rb;
+}
+
 hipError_t launch_finalize(const TableView& t, const float* qprep, const QInfo* qinfo, int64_t nq,
                            int dpad, const SelGeom& g, int G, int k,
                            const float* cand_s, const long long* cand_t, const float* cand_h,
@@ -1008,7 +1063,7 @@ hipError_t launch_finalize(const TableView& t, const float* qprep, const QInfo* 
     p.out_ids = out_ids; p.out_scores = out_scores; p.out_counts = out_counts;
     p.need_exact = need_exact; p.counters = counters;
     p.flat_cnt = nullptr; p.flat_cap = 0; p.flat_tau = nullptr; p.flat_lost = nullptr; p.flat_bad = nullptr;
-    p.dd_mult = fb.dd_mult; p.extra_rel = fb.extra_rel; p.extra_abs = fb.extra_abs; p.l2_bias = 0.0; p.floor_out = nullptr;
+    p.dd_mult = fb.dd_mult; p.extra_rel = fb.extra_rel; p.extra_abs = fb.extra_abs; p.l2_bias = 0.0; p.force_exact = fb.force_exact; p.floor_out = nullptr;
     int kr = 1; while (kr < g.K) kr <<= 1;
     const size_t lds = 1088 + (size_t)g.K * 12 + (size_t)kr * 12 + (size_t)FIN_CAP * 8;
     hipError_t e = allow_lds(finalize_kernel, lds);
@@ -1046,7 +1101,7 @@ hipError_t launch_finalize_flat(const TableView& t, const float* qprep, const QI
     p.out_ids = out_ids; p.out_scores = out_scores; p.out_counts = out_counts;
     p.need_exact = need_exact; p.counters = counters;
     p.flat_cnt = cnt; p.flat_cap = cap; p.flat_tau = tau; p.flat_lost = lost; p.flat_bad = bad;
-    p.dd_mult = fb.dd_mult; p.extra_rel = fb.extra_rel; p.extra_abs = fb.extra_abs; p.l2_bias = fb.l2_bias; p.floor_out = nullptr;
+    p.dd_mult = fb.dd_mult; p.extra_rel = fb.extra_rel; p.extra_abs = fb.extra_abs; p.l2_bias = fb.l2_bias; p.force_exact = fb.force_exact; p.floor_out = nullptr;
     const size_t lds = 1088 + (size_t)BAND_CAP * 20;
     hipError_t e = allow_lds(finalize_band_kernel, lds);
     if (e != hipSuccess) return e;

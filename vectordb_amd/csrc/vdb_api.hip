@@ -112,6 +112,8 @@ struct Global {
     int use_vmm = 1;                     // tables grow in reserved virtual ranges (0: allocate + copy)
     size_t vmm_gran = 0;                 // allocation granularity of the virtual-memory API (0 = unavailable)
     int tune_pp = 1;                     // batches over 128 queries run on the ping-pong kernel
+    int force_exact = 0;                 // measurement: every query takes the exact pass
+    int row_bounds = 1;                  // L2 keys carry their own row's error term (0: table-wide norm bound)
     int tune_nt = 1, tune_waves = 8, tune_bpc = 4, tune_contig = 1, tune_gemm = 1, tune_split_f16 = 0, tune_split_bf16 = 0, tune_sample = 1, tune_gemm32s = 2;
     // host-insert staging (guarded by insert_mu)
     std::mutex insert_mu;
@@ -261,9 +263,10 @@ static const int GEMM_CAP = 8192;          // candidate slots per query on the b
 static const double GEMM_TARGET = 2048.0;  // candidates per query each pass aims for
 
 // Per-query path: one bandwidth-bound scan of the table per query.
-static int search_scan_path(const TableView& tv, const SelGeom& g, int dpad, int64_t nq, const float* q_dev,
+static int search_scan_path(const TableView& tv_in, const SelGeom& g, int dpad, int64_t nq, const float* q_dev,
                             int k, long long* out_ids, float* out_scores, int* out_counts,
                             hipStream_t st, Workspace& ws) {
+    TableView tv = tv_in;
     const int Gx = scan_grid(tv, g, G.n_cu);
     const int64_t chunk = 256;
     const int64_t nqc = nq < chunk ? nq : chunk;
@@ -282,6 +285,7 @@ static int search_scan_path(const TableView& tv, const SelGeom& g, int dpad, int
     // the split leaves 2^-18 of |q| unrepresented): both are part of the certificate's bound
     FlatBound fb;
     if (tv.dt == VDB_BF16) { fb.dd_mult = 2.0; fb.extra_rel = 4.0e-6; }
+    fb.force_exact = G.force_exact;
     const size_t rowbytes = (size_t)tv.m * 16;
     const bool sampled = g.K >= 64 && rowbytes <= 1024 && tv.n >= 262144 && G.tune_sample != 0;
     TableView tvs = tv;
@@ -299,6 +303,8 @@ static int search_scan_path(const TableView& tv, const SelGeom& g, int dpad, int
         float* cs = (float*)ws.cand_s.p;
         long long* ct = (long long*)ws.cand_t.p;
         int* ne = (int*)ws.need_exact.p;
+        // L2 keys carry the error term of their own row (see RowBound)
+        if (tv.metric == VDB_METRIC_L2 && G.row_bounds) tv.rb = tvs.rb = l2_row_bound(fb, tv.d, qinfo, (int)nqi);
         VDB_HIP(launch_prep_query(q_dev + (size_t)q0 * tv.d, nqi, tv.d, dpad, tv.metric, qprep, qinfo, ne, st));
         const float* floor = nullptr;
         if (sampled) {
@@ -345,9 +351,10 @@ static int search_scan_path(const TableView& tv, const SelGeom& g, int dpad, int
 // the last); the full pass runs on the 16-bit MFMA for every table type: bf16 / fp16 rows with the
 // query split into hi + lo parts, fp32 rows split into bf16 hi + lo as well (from 64 queries; the
 // fp32 MFMA kernel serves smaller batches and the sampled passes).
-static int search_gemm_path(const TableView& tv, const SelGeom& g, int dpad, int64_t nq, const float* q_dev,
+static int search_gemm_path(const TableView& tv_in, const SelGeom& g, int dpad, int64_t nq, const float* q_dev,
                             int k, long long* out_ids, float* out_scores, int* out_counts,
                             hipStream_t st, Workspace& ws) {
+    TableView tv = tv_in;
     const int K = g.K;
     const bool l2 = tv.metric == VDB_METRIC_L2;
     const long long ntiles = (tv.n + 127) / 128;
@@ -394,6 +401,7 @@ static int search_gemm_path(const TableView& tv, const SelGeom& g, int dpad, int
     const bool use_pp = G.tune_pp != 0 && nq > 128 && pp_eligible(tv, dpad) && ((half && !split) || (s32 && !s32split));
     FlatBound fb;
     fb.l2_bias = use_pp ? 1.0 : 0.0;
+    fb.force_exact = G.force_exact;
     // accumulation chain in units of d: one per product, and a factor of two of margin on the
     // matrix unit's internal summation order and rounding
     fb.dd_mult = 2.0 * (s32 ? (s32split ? 3.0 : 1.0) : ((half && split) ? 2.0 : 1.0));
@@ -427,6 +435,7 @@ static int search_gemm_path(const TableView& tv, const SelGeom& g, int dpad, int
             if (half) return launch_gemm16_thresh(v, qhi, qlo, qstride, split, nqi, dpad, thr, stride, tiles, cs, ct, cnt, lost, GEMM_CAP, dense, G.n_cu, st);
             return launch_gemm_thresh(v, qprep, nqi, dpad, thr, 0, stride, tiles, cs, ct, cnt, lost, GEMM_CAP, dense, G.n_cu, st);
         };
+        if (l2 && G.row_bounds) tv.rb = tv0.rb = l2_row_bound(fb, tv.d, qinfo, nqi);
         VDB_HIP(launch_prep_query(q_dev + (size_t)q0 * tv.d, nqi, tv.d, dpad, tv.metric, qprep, qinfo, ne, st));
         VDB_HIP(hipMemsetAsync(bad, 0, (size_t)nqc * 4, st));
         if (half) VDB_HIP(launch_split_query16(tv.dt, qprep, nqi, dpad, qstride, qhi, qlo, bad, st));
@@ -831,6 +840,8 @@ int vdb_set_option(const char* key, double value) {
     else if (k == "gemm_split_bf16") G.tune_split_bf16 = value != 0;
     else if (k == "gemm32s_threads") set_gemm32s_threads((int)value);
     else if (k == "gemm_pp") G.tune_pp = value != 0;
+    else if (k == "force_exact") G.force_exact = value != 0;
+    else if (k == "l2_row_bounds") G.row_bounds = value != 0;
     else if (k == "bf16_mirror") G.bf16_mirror = value != 0;
     else if (k == "virtual_ranges") G.use_vmm = value != 0;
     else return fail(VDB_EINVAL, "unknown option: " + k);

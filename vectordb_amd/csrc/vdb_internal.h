@@ -13,6 +13,17 @@ struct QInfo {
     float  pad;
 };
 
+// Per-row error term of the L2 fast keys.  A fast key 2 x.q - ||x||^2 is off the canonical one by at
+// most e(x) = a ||x||^2 + (brel bq + cabs) ||x|| (bq: the largest query norm of the launch).  A pass
+// that is given this record adds e(x) to every key, so that a key bounds its canonical key from above
+// and the finalize steps never need a table-wide norm bound: one huge row does not loosen the
+// certificate of the others.
+struct RowBound {
+    const QInfo* qinfo = nullptr;    // the launch's prepared queries; null: keys carry no error term
+    int   nq = 0;
+    float a = 0.f, brel = 0.f, cabs = 0.f;     // rounded up, fp32 evaluation error included
+};
+
 // Geometry of a stored table as the kernels see it.
 struct TableView {
     const char*      rows;      // [n][m*16 bytes], row-major, zero padded to a 16-byte multiple
@@ -27,7 +38,24 @@ struct TableView {
     int              m;         // 16-byte units per row
     int              dt;        // VDB_F32 / VDB_BF16 / VDB_F16
     int              metric;    // VDB_METRIC_*
+    RowBound         rb;        // L2 searches: per-row error term of this call's passes
 };
+
+#if defined(__HIPCC__)
+// (brel bq + cabs) for the launch; every wave evaluates it by itself
+__device__ __forceinline__ float rowbound_s(const RowBound& rb, int lane) {
+    float m = 0.f;
+    for (int i = lane; i < rb.nq; i += 64) m = fmaxf(m, rb.qinfo[i].bq);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    return fmaf(rb.brel, m, rb.cabs);
+}
+// ||x||^2 - e(x): what an L2 pass subtracts from 2 x.q
+__device__ __forceinline__ float rowbound_adj(float n2, float a, float s) {
+    // the hardware square root (1 ulp, subnormal arguments read as zero) is inside the margin of s
+    return fmaf(-a, n2, n2) - s * __builtin_amdgcn_sqrtf(n2);
+}
+#endif
 
 inline int elems_per_unit(int dt) { return dt == VDB_F32 ? 4 : 8; }
 
@@ -72,7 +100,10 @@ struct FlatBound {
     double dd_mult = 1.0;     // accumulation chain length in units of d (2 when hi and lo parts are summed)
     double extra_rel = 0.0;   // relative error of the query as the MFMA sees it (x ||x|| ||q||)
     double extra_abs = 0.0;   // absolute error per unit of ||x|| (fp16 subnormal spacing)
+    int    force_exact = 0;   // measurement: every query is sent to the exact pass
 };
+// The RowBound coefficients that cover the same error terms for a table of dimension d.
+RowBound l2_row_bound(const FlatBound& fb, int d, const QInfo* qinfo, int nq);
 
 // Merge candidates, re-score them canonically (fp64), order by (score, id), certify.
 hipError_t launch_finalize(const TableView& t, const float* qprep, const QInfo* qinfo, int64_t nq,
