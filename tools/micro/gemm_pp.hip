@@ -182,7 +182,9 @@ static void run_time(long long n, int nq, int K, int reps, int l2) {
     const int qtiles = (nq + 255) / 256;
     int gx = prop.multiProcessorCount / qtiles / 8 * 8;
     if (gx < 8) gx = 8;
+    if (getenv("PP_GX")) gx = atoi(getenv("PP_GX"));
     if (gx > p.ntiles) gx = (int)p.ntiles;
+    if (getenv("PP_STRIDE0")) p.tile_stride = 0;      // every tile reads the first 256 rows: the row operand comes from cache
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int w = 0; w < 2; ++w) { CK(hipMemset(cnt, 0, nq * 4)); if (l2) launch<true>(p, gx, qtiles); else launch<false>(p, gx, qtiles); }
     CK(hipDeviceSynchronize());

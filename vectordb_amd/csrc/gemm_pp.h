@@ -49,8 +49,9 @@ struct GemmPPParams {
     int          nq;
     int          qstride;
     int          nks;            // k-steps of 32 elements
-    long long    ntiles;         // 256-row tiles visited: tile t * tile_stride, t < ntiles
+    long long    ntiles;         // 256-row tiles visited: tile tile0 + t * tile_stride, t < ntiles
     long long    tile_stride;
+    long long    tile0;
     float*       cand_s;         // [nq][cap]
     long long*   cand_t;
     int*         cnt;            // [nq]
@@ -174,7 +175,7 @@ gemm_pp_kernel(GemmPPParams p) {
     const char* atile = nullptr;
     const float* nsrc = nullptr;
     auto set_tile_src = [&]() __attribute__((always_inline)) {
-        const long long tile = (blockIdx.x + f_seq * gridDim.x) * p.tile_stride;
+        const long long tile = p.tile0 + (blockIdx.x + f_seq * gridDim.x) * p.tile_stride;
         const long long row0 = tile * PP_TM;
         if constexpr (TILED) {
             atile = (const char*)p.X + (((size_t)tile * nks) << 14);
@@ -217,11 +218,8 @@ gemm_pp_kernel(GemmPPParams p) {
         }
     };
     auto issue = [&](int buf) __attribute__((always_inline)) { issue_a(buf); issue_b(buf); };
-#ifndef PP_GPOS
-#define PP_GPOS 0
-#endif
     constexpr int NA = L2M ? 3 : 2, NB = 2;
-    constexpr int WAITN = PP_GPOS == 2 ? NA + NB : PP_GPOS == 3 ? 2 * NA + NB : 2 * (NA + NB);
+    constexpr int WAITN = 2 * (NA + NB);
     issue(0); issue(1); issue(2);
     asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * (NA + NB)) : "memory");
     __builtin_amdgcn_s_barrier();
@@ -332,9 +330,6 @@ gemm_pp_kernel(GemmPPParams p) {
         const char* sb = pp_smem + buf * PP_STAGE;
         // ---------------- LOAD(s)
         if (epi) { epilogue(epi_row0); epi = false; }
-#if PP_GPOS == 1
-        issue((int)((s + 3) & 3));
-#endif
 #if defined(PP_ABL) && (PP_ABL & 2)
         if (s == 0)                    // timing ablation: fragments read once
 #endif
@@ -364,11 +359,8 @@ gemm_pp_kernel(GemmPPParams p) {
                     }
             }
         }
-#if (!defined(PP_ABL) || !(PP_ABL & 1)) && PP_GPOS == 0
+#if !defined(PP_ABL) || !(PP_ABL & 1)
         issue((int)((s + 3) & 3));
-#endif
-#if PP_GPOS == 3
-        issue_a((int)((s + 3) & 3));
 #endif
         asm volatile("s_waitcnt vmcnt(%0)" :: "i"(WAITN) : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -376,9 +368,6 @@ gemm_pp_kernel(GemmPPParams p) {
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         // ---------------- COMP(s)
-#if PP_GPOS == 2
-        issue((int)((s + 3) & 3));
-#endif
         __builtin_amdgcn_s_setprio(1);
 #if defined(PP_ABL) && (PP_ABL & 4)
 #pragma unroll
@@ -411,11 +400,6 @@ gemm_pp_kernel(GemmPPParams p) {
 #pragma unroll
                 for (int ni = 0; ni < NNI; ++ni) acc[mi][ni] = pp_mfma<DT, SHAPE>(af[mi][0], bf[ni][0], acc[mi][ni]);
         }
-#if PP_GPOS == 3
-        __builtin_amdgcn_sched_barrier(0);
-        issue_b((int)((s + 3) & 3));
-        __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
         for (int kk = 1; kk < KK; ++kk)
 #pragma unroll
@@ -430,7 +414,7 @@ gemm_pp_kernel(GemmPPParams p) {
         if (++c_ks == nks) {
             c_ks = 0;
             epi = true;
-            epi_row0 = (blockIdx.x + c_seq * gridDim.x) * p.tile_stride * PP_TM;
+            epi_row0 = (p.tile0 + (blockIdx.x + c_seq * gridDim.x) * p.tile_stride) * PP_TM;
             ++c_seq;
         }
     }

@@ -1019,13 +1019,18 @@ static hipError_t launch_gemm_pp_v(const GemmPPParams& p, int n_cu, hipStream_t 
 }
 
 hipError_t launch_gemm_pp(const TableView& t, const unsigned short* qimage, int nq, int dpad, const float* thr,
-                          long long tile_stride, float* cand_s, long long* cand_t, int* cnt, int* lost, int cap,
+                          long long tile_stride, long long tile0, long long tile_count,
+                          float* cand_s, long long* cand_t, int* cnt, int* lost, int cap,
                           int n_cu, hipStream_t st) {
     GemmPPParams p;
     p.X = t.rows16; p.n2 = t.n2; p.rb = t.rb; p.Q = qimage; p.thr = thr; p.n = t.n; p.ldx = t.ld16; p.nq = nq;
     p.qstride = 0; p.nks = pp_nks(dpad);
     p.tile_stride = tile_stride < 1 ? 1 : tile_stride;
     p.ntiles = ((t.n + PP_TM - 1) / PP_TM + p.tile_stride - 1) / p.tile_stride;
+    // a range of the visited tiles: [tile0, tile0 + tile_count) of them (tile_count < 0: to the end)
+    p.tile0 = tile0 * p.tile_stride;
+    p.ntiles -= tile0;
+    if (tile_count >= 0 && tile_count < p.ntiles) p.ntiles = tile_count;
     p.cand_s = cand_s; p.cand_t = cand_t; p.cnt = cnt; p.lost = lost; p.cap = cap; p.dense = nullptr;
     if (p.ntiles <= 0) return hipSuccess;
     const bool l2 = t.metric == VDB_METRIC_L2;

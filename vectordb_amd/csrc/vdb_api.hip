@@ -113,6 +113,7 @@ struct Global {
     size_t vmm_gran = 0;                 // allocation granularity of the virtual-memory API (0 = unavailable)
     int tune_pp = 1;                     // batches over 128 queries run on the ping-pong kernel
     int force_exact = 0;                 // measurement: every query takes the exact pass
+    int tune_pp_parts = 1;               // the last batched pass tightens its threshold after an eighth of the rows
     int row_bounds = 1;                  // L2 keys carry their own row's error term (0: table-wide norm bound)
     int tune_nt = 1, tune_waves = 8, tune_bpc = 4, tune_contig = 1, tune_gemm = 1, tune_split_f16 = 0, tune_split_bf16 = 0, tune_sample = 1, tune_gemm32s = 2;
     // host-insert staging (guarded by insert_mu)
@@ -457,7 +458,7 @@ static int search_gemm_path(const TableView& tv_in, const SelGeom& g, int dpad, 
             // strided sample of `tiles` row tiles under the current threshold -> next threshold
             const long long stride = ntiles / tiles;
             VDB_HIP(hipMemsetAsync(cnt, 0, (size_t)nqc * 8, st));
-            if (pp) VDB_HIP(launch_gemm_pp(tv, qimg, nqi, dpad, tau, stride, cs, ct, cnt, lost, GEMM_CAP, G.n_cu, st));
+            if (pp) VDB_HIP(launch_gemm_pp(tv, qimg, nqi, dpad, tau, stride, 0, -1, cs, ct, cnt, lost, GEMM_CAP, G.n_cu, st));
             else if (s32) VDB_HIP(launch_gemm32s(tv, qhi, qlo, qstride, s32split, nqi, dpad, tau, stride, cs, ct, cnt, lost, GEMM_CAP, G.n_cu, st));
             else VDB_HIP(gemm(tv, tau, stride, ntiles / stride, 0));
             VDB_HIP(launch_kth_threshold(cs, GEMM_CAP, cnt, 0, GEMM_CAP, K, tau, spare, nqi, st));
@@ -467,7 +468,24 @@ static int search_gemm_path(const TableView& tv_in, const SelGeom& g, int dpad, 
         VDB_HIP(hipMemsetAsync(cnt, 0, (size_t)nqc * 8, st));
         ProfScope prof;
         if ((rc = prof.begin(st))) return rc;
-        if (pp) VDB_HIP(launch_gemm_pp(tv, qimg, nqi, dpad, tau, 1, cs, ct, cnt, lost, GEMM_CAP, G.n_cu, st));
+        if (pp) {
+            // The threshold from the last sample lets about K * (rows / sample) rows through, and every
+            // candidate costs the kernel about 230 cycles of one CU.  The first eighth of the tiles
+            // therefore runs alone; the K-th best key of its candidates is a much tighter threshold for
+            // the other seven eighths (candidates per query at 10 M rows: 2000 -> 500).  Candidates of both
+            // parts stay in the array; the finalize step is told the tighter threshold, which is valid
+            // for every row that is not a candidate.
+            const long long t256 = (tv.n + 255) / 256;
+            const long long part = G.tune_pp_parts ? t256 / 8 : 0;
+            if (part >= 4LL * G.n_cu) {
+                VDB_HIP(launch_gemm_pp(tv, qimg, nqi, dpad, tau, 1, 0, part, cs, ct, cnt, lost, GEMM_CAP, G.n_cu, st));
+                VDB_HIP(launch_kth_threshold(cs, GEMM_CAP, cnt, 0, GEMM_CAP, K, tau, spare, nqi, st));
+                std::swap(tau, spare);
+                VDB_HIP(launch_gemm_pp(tv, qimg, nqi, dpad, tau, 1, part, -1, cs, ct, cnt, lost, GEMM_CAP, G.n_cu, st));
+            } else {
+                VDB_HIP(launch_gemm_pp(tv, qimg, nqi, dpad, tau, 1, 0, -1, cs, ct, cnt, lost, GEMM_CAP, G.n_cu, st));
+            }
+        }
         else if (s32) VDB_HIP(launch_gemm32s(tv, qhi, qlo, qstride, s32split, nqi, dpad, tau, 1, cs, ct, cnt, lost, GEMM_CAP, G.n_cu, st));
         else VDB_HIP(gemm(tv, tau, 1, ntiles, 0));
         if ((rc = prof.end(st))) return rc;
@@ -841,6 +859,7 @@ int vdb_set_option(const char* key, double value) {
     else if (k == "gemm32s_threads") set_gemm32s_threads((int)value);
     else if (k == "gemm_pp") G.tune_pp = value != 0;
     else if (k == "force_exact") G.force_exact = value != 0;
+    else if (k == "gemm_pp_parts") G.tune_pp_parts = value != 0;
     else if (k == "l2_row_bounds") G.row_bounds = value != 0;
     else if (k == "bf16_mirror") G.bf16_mirror = value != 0;
     else if (k == "virtual_ranges") G.use_vmm = value != 0;

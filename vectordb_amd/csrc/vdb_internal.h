@@ -143,7 +143,8 @@ size_t pp_query_image_bytes(int nq, int dpad);
 hipError_t launch_tile_query16(int dt, int l2, const float* qprep, int nq, int dpad, unsigned short* image,
                                int* bad, hipStream_t st);
 hipError_t launch_gemm_pp(const TableView& t, const unsigned short* qimage, int nq, int dpad, const float* thr,
-                          long long tile_stride, float* cand_s, long long* cand_t, int* cnt, int* lost, int cap,
+                          long long tile_stride, long long tile0, long long tile_count,
+                          float* cand_s, long long* cand_t, int* cnt, int* lost, int cap,
                           int n_cu, hipStream_t st);
 hipError_t launch_gemm32s(const TableView& t, const unsigned short* qhi, const unsigned short* qlo, int qstride,
                           int split, int nq, int dpad, const float* thr, long long tile_stride,
