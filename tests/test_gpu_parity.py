@@ -630,6 +630,35 @@ def test_batched_fp32_with_large_magnitudes_and_ties(engine, table_name, split):
         engine.set_option("gemm32_split", 2)
 
 
+@pytest.mark.parametrize("metric", ["ip", "cosine", "l2"])
+@pytest.mark.parametrize("kind,d", [("synth", 768), ("synth", 64), ("ties", 64), ("synth", 100)])
+def test_single_queries_over_the_bf16_mirror_of_an_fp32_table(engine, table_name, metric, kind, d):
+    """Option scan_mirror: the scan reads the bf16 mirror (half the bytes) and the candidates are re-scored
+    from the fp32 rows; the answers are the oracle's bit for bit, through the certificate or (tie-heavy
+    rows) the exact pass.  d = 100 has no mirror row of the query's length and scans the fp32 rows."""
+    n = 50_000
+    rows = cases.make_rows(kind, 71, n, d)
+    if kind == "synth":
+        rows[::50] *= 30.0
+    ids = cases.make_ids("hash", 71, n)
+    q = cases.make_queries(kind, 71, 3, d, rows)
+    m = cases.METRICS[metric]
+    stored = _load(engine, table_name, rows, ids, m, _lib.F32)
+    engine.set_option("scan_mirror", 1)
+    engine.set_option("use_blas_threshold", 1000)
+    try:
+        before = engine.stats()
+        _check(engine, table_name, stored, ids, q, 10, m)
+        _check(engine, table_name, stored, ids, q[:1], 100, m)     # list too short for the mirror's bound: fp32 scan
+        after = engine.stats()
+        assert after[2] == before[2]                               # no batched path
+        if kind == "synth" and d == 768:
+            assert after[1] == before[1]                           # certified without the exact pass
+    finally:
+        engine.set_option("scan_mirror", 0)
+        engine.set_option("use_blas_threshold", 2)
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("nq", [3, 40, 150])
 def test_l2_rows_with_heavy_tailed_norms_stay_on_the_fast_path(engine, table_name, nq, dtype):

@@ -114,6 +114,7 @@ struct Global {
     int tune_pp = 1;                     // batches over 128 queries run on the ping-pong kernel
     int force_exact = 0;                 // measurement: every query takes the exact pass
     int tune_pp_parts = 1;               // the last batched pass tightens its threshold after an eighth of the rows
+    int scan_mirror = 0;                 // single queries over fp32 tables scan the bf16 mirror
     int row_bounds = 1;                  // L2 keys carry their own row's error term (0: table-wide norm bound)
     int tune_nt = 1, tune_waves = 8, tune_bpc = 4, tune_contig = 1, tune_gemm = 1, tune_split_f16 = 0, tune_split_bf16 = 0, tune_sample = 1, tune_gemm32s = 2;
     // host-insert staging (guarded by insert_mu)
@@ -268,7 +269,17 @@ static int search_scan_path(const TableView& tv_in, const SelGeom& g, int dpad, 
                             int k, long long* out_ids, float* out_scores, int* out_counts,
                             hipStream_t st, Workspace& ws) {
     TableView tv = tv_in;
-    const int Gx = scan_grid(tv, g, G.n_cu);
+    // What the scan reads.  fp32 tables can be scanned on their bf16 mirror (option scan_mirror): half
+    // the bytes; the rounding of the rows (2^-9 of ||x|| ||q||) goes into the certificate's bound, and
+    // the candidates are re-scored from the fp32 rows as always, so the answer is the same or the
+    // query takes the exact pass.  Needs a mirror row as long as the prepared query (dim % 32 == 0).
+    TableView tsc = tv;
+    // The list must reach well past the k-th hit for the wider bound to certify (K = 32 for k = 10 does; K = 128 for
+    // k = 100 sent two queries in three to the exact pass).
+    const bool mirror = G.scan_mirror != 0 && !ws.fixed && tv.dt == VDB_F32 && tv.rows16 != nullptr && tv.ld16 == dpad &&
+                        g.K >= 3 * k;
+    if (mirror) { tsc.rows = (const char*)tv.rows16; tsc.m = (int)(tv.ld16 / 8); tsc.dt = VDB_BF16; }
+    const int Gx = scan_grid(tsc, g, G.n_cu);
     const int64_t chunk = 256;
     const int64_t nqc = nq < chunk ? nq : chunk;
     int rc;
@@ -285,11 +296,12 @@ static int search_scan_path(const TableView& tv_in, const SelGeom& g, int dpad, 
     // bf16 rows are scanned against the query as packed bf16 hi + lo parts (two products per element,
     // the split leaves 2^-18 of |q| unrepresented): both are part of the certificate's bound
     FlatBound fb;
-    if (tv.dt == VDB_BF16) { fb.dd_mult = 2.0; fb.extra_rel = 4.0e-6; }
+    if (tsc.dt == VDB_BF16) { fb.dd_mult = 2.0; fb.extra_rel = 4.0e-6; }
+    if (mirror) fb.extra_rel += 1.96e-3;
     fb.force_exact = G.force_exact;
-    const size_t rowbytes = (size_t)tv.m * 16;
+    const size_t rowbytes = (size_t)tsc.m * 16;
     const bool sampled = g.K >= 64 && rowbytes <= 1024 && tv.n >= 262144 && G.tune_sample != 0;
-    TableView tvs = tv;
+    TableView tvs = tsc;
     int Gs = 0;
     if (sampled) {
         tvs.n = tv.n / 256 > 4LL * g.K ? tv.n / 256 : 4LL * g.K;
@@ -305,7 +317,7 @@ static int search_scan_path(const TableView& tv_in, const SelGeom& g, int dpad, 
         long long* ct = (long long*)ws.cand_t.p;
         int* ne = (int*)ws.need_exact.p;
         // L2 keys carry the error term of their own row (see RowBound)
-        if (tv.metric == VDB_METRIC_L2 && G.row_bounds) tv.rb = tvs.rb = l2_row_bound(fb, tv.d, qinfo, (int)nqi);
+        if (tv.metric == VDB_METRIC_L2 && G.row_bounds) tv.rb = tsc.rb = tvs.rb = l2_row_bound(fb, tv.d, qinfo, (int)nqi);
         VDB_HIP(launch_prep_query(q_dev + (size_t)q0 * tv.d, nqi, tv.d, dpad, tv.metric, qprep, qinfo, ne, st));
         const float* floor = nullptr;
         if (sampled) {
@@ -327,7 +339,7 @@ static int search_scan_path(const TableView& tv_in, const SelGeom& g, int dpad, 
             }
             ProfScope prof;
             if (!ws.fixed && (rc = prof.begin(st))) return rc;
-            VDB_HIP(launch_scan(tv, qprep, nqi, dpad, g, Gx, cs, ct, (float*)ws.cand_h.p, floor, st));
+            VDB_HIP(launch_scan(tsc, qprep, nqi, dpad, g, Gx, cs, ct, (float*)ws.cand_h.p, floor, st));
             if (!ws.fixed && (rc = prof.end(st))) return rc;
             if (ordered) {
                 const int slot = (G.chain_head + 1) % 16;
@@ -860,6 +872,7 @@ int vdb_set_option(const char* key, double value) {
     else if (k == "gemm_pp") G.tune_pp = value != 0;
     else if (k == "force_exact") G.force_exact = value != 0;
     else if (k == "gemm_pp_parts") G.tune_pp_parts = value != 0;
+    else if (k == "scan_mirror") G.scan_mirror = value != 0;
     else if (k == "l2_row_bounds") G.row_bounds = value != 0;
     else if (k == "bf16_mirror") G.bf16_mirror = value != 0;
     else if (k == "virtual_ranges") G.use_vmm = value != 0;
