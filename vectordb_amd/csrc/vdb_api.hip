@@ -412,6 +412,12 @@ static int search_gemm_path(const TableView& tv_in, const SelGeom& g, int dpad, 
     // Batches of more than 128 queries run every pass but the first on the ping-pong kernel: 256 x 256
     // tiles, operands straight from global memory into LDS; fp32 tables multiply their bf16 mirror.
     const bool use_pp = G.tune_pp != 0 && nq > 128 && pp_eligible(tv, dpad) && ((half && !split) || (s32 && !s32split));
+    // Smaller batches over fp32 tables read the mirror as well (as a bf16 table: half the bytes of a pass
+    // that is bound by reading the rows once); it holds the very values the converting kernel would
+    // round the fp32 rows to, so keys and bounds are the same.
+    const bool use_m = s32 && !s32split && tv.rows16 != nullptr && G.bf16_mirror != 0;
+    TableView tvm = tv;
+    if (use_m) { tvm.rows = (const char*)tv.rows16; tvm.m = (int)(tv.ld16 / 8); tvm.dt = VDB_BF16; }
     FlatBound fb;
     fb.l2_bias = use_pp ? 1.0 : 0.0;
     fb.force_exact = G.force_exact;
@@ -448,7 +454,7 @@ static int search_gemm_path(const TableView& tv_in, const SelGeom& g, int dpad, 
             if (half) return launch_gemm16_thresh(v, qhi, qlo, qstride, split, nqi, dpad, thr, stride, tiles, cs, ct, cnt, lost, GEMM_CAP, dense, G.n_cu, st);
             return launch_gemm_thresh(v, qprep, nqi, dpad, thr, 0, stride, tiles, cs, ct, cnt, lost, GEMM_CAP, dense, G.n_cu, st);
         };
-        if (l2 && G.row_bounds) tv.rb = tv0.rb = l2_row_bound(fb, tv.d, qinfo, nqi);
+        if (l2 && G.row_bounds) tv.rb = tv0.rb = tvm.rb = l2_row_bound(fb, tv.d, qinfo, nqi);
         VDB_HIP(launch_prep_query(q_dev + (size_t)q0 * tv.d, nqi, tv.d, dpad, tv.metric, qprep, qinfo, ne, st));
         VDB_HIP(hipMemsetAsync(bad, 0, (size_t)nqc * 4, st));
         if (half) VDB_HIP(launch_split_query16(tv.dt, qprep, nqi, dpad, qstride, qhi, qlo, bad, st));
@@ -471,7 +477,7 @@ static int search_gemm_path(const TableView& tv_in, const SelGeom& g, int dpad, 
             const long long stride = ntiles / tiles;
             VDB_HIP(hipMemsetAsync(cnt, 0, (size_t)nqc * 8, st));
             if (pp) VDB_HIP(launch_gemm_pp(tv, qimg, nqi, dpad, tau, stride, 0, -1, cs, ct, cnt, lost, GEMM_CAP, G.n_cu, st));
-            else if (s32) VDB_HIP(launch_gemm32s(tv, qhi, qlo, qstride, s32split, nqi, dpad, tau, stride, cs, ct, cnt, lost, GEMM_CAP, G.n_cu, st));
+            else if (s32) VDB_HIP(launch_gemm32s(use_m ? tvm : tv, qhi, qlo, qstride, s32split, nqi, use_m ? (int)tv.ld16 : dpad, tau, stride, cs, ct, cnt, lost, GEMM_CAP, G.n_cu, st));
             else VDB_HIP(gemm(tv, tau, stride, ntiles / stride, 0));
             VDB_HIP(launch_kth_threshold(cs, GEMM_CAP, cnt, 0, GEMM_CAP, K, tau, spare, nqi, st));
             std::swap(tau, spare);
@@ -498,7 +504,7 @@ static int search_gemm_path(const TableView& tv_in, const SelGeom& g, int dpad, 
                 VDB_HIP(launch_gemm_pp(tv, qimg, nqi, dpad, tau, 1, 0, -1, cs, ct, cnt, lost, GEMM_CAP, G.n_cu, st));
             }
         }
-        else if (s32) VDB_HIP(launch_gemm32s(tv, qhi, qlo, qstride, s32split, nqi, dpad, tau, 1, cs, ct, cnt, lost, GEMM_CAP, G.n_cu, st));
+        else if (s32) VDB_HIP(launch_gemm32s(use_m ? tvm : tv, qhi, qlo, qstride, s32split, nqi, use_m ? (int)tv.ld16 : dpad, tau, 1, cs, ct, cnt, lost, GEMM_CAP, G.n_cu, st));
         else VDB_HIP(gemm(tv, tau, 1, ntiles, 0));
         if ((rc = prof.end(st))) return rc;
         VDB_HIP(launch_finalize_flat(tv, qprep, qinfo, nqi, dpad, g, k, cs, ct, cnt, GEMM_CAP, tau, lost, bad, fb,
@@ -535,7 +541,11 @@ static int search_core(Table& t, int64_t nq, const float* q_dev, int k, long lon
         // a batched pass reads the rows once at about 6.1 TB/s and multiplies at about 5e14
         // multiply-adds per second on the 16-bit matrix unit (times the products per term).
         const double B = (double)tv.n * tv.m * 16.0;
-        const double est_scan = 60e-6 + (double)nq * (20e-6 + B / 6.5e12);
+        // bytes a batched pass reads: fp32 tables are multiplied from their bf16 mirror
+        const bool mirrored = tv.dt == VDB_F32 && tv.rows16 != nullptr && G.bf16_mirror != 0 && G.tune_gemm32s == 2;
+        const double Bp = mirrored ? (double)tv.n * tv.ld16 * 2.0 : B;
+        const bool scan_m = G.scan_mirror != 0 && tv.dt == VDB_F32 && tv.rows16 != nullptr && tv.ld16 == t.dpad && g.K >= 3 * k;
+        const double est_scan = 60e-6 + (double)nq * (20e-6 + (scan_m ? Bp : B) / 6.5e12);
         double est_gemm;
         if (tv.dt == VDB_F32 && G.tune_gemm32s == 0) {
             const double pass_rate = nq <= 32 ? 5.0e12 : nq <= 64 ? 4.2e12 : 3.8e12;      // fp32 MFMA kernel
@@ -543,7 +553,7 @@ static int search_core(Table& t, int64_t nq, const float* q_dev, int k, long lon
         } else {
             const double products = tv.dt == VDB_F32 ? (G.tune_gemm32s == 1 ? 3.0 : 1.0)
                                                      : ((tv.dt == VDB_BF16 ? G.tune_split_bf16 : G.tune_split_f16) ? 2.0 : 1.0);
-            est_gemm = 270e-6 + B / 6.1e12 + products * (double)tv.n * t.dpad * (double)nq / 5.0e14;
+            est_gemm = 270e-6 + Bp / 6.1e12 + products * (double)tv.n * t.dpad * (double)nq / 5.0e14;
         }
         if (est_scan < est_gemm) gemm = false;
     }
