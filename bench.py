@@ -258,9 +258,11 @@ def rank_main(args, world: int) -> None:
 
         qps = steps * nq / elapsed
         bytes_per_launch = n_local * dim * esz + (n_local * 4 if metric_name == "l2" else 0)
-        if mirror:
+        mirror_bytes = n_local * ((dim + 31) // 32 * 32) * 2 + (n_local * 4 if metric_name == "l2" else 0)
+        mirror = mirror or (opts.get("scan_mirror") == "1" and dtype == "f32" and dim % 32 == 0 and k <= 10)
+        if mirror and nq == 1:
             # option scan_mirror: the scan reads the bf16 mirror of the fp32 rows (rows padded to 32 elements)
-            bytes_per_launch = n_local * ((dim + 31) // 32 * 32) * 2 + (n_local * 4 if metric_name == "l2" else 0)
+            bytes_per_launch = mirror_bytes
         avg_s = (kern_ms / max(1, launches)) / 1e3
         gbs = bytes_per_launch / avg_s / 1e9 if avg_s > 0 else 0.0
         entry = {
@@ -286,7 +288,7 @@ def rank_main(args, world: int) -> None:
             "host_latency_ms": host_lat,
             "sample_result": {"ids": [int(x) for x in last_ids[0][:3]], "scores": [float(x) for x in last_scores[0][:3]]},
         }
-        if mirror:
+        if mirror and nq == 1:
             entry["dtype"] = "f32 rows; scan over their bf16 mirror, f32 accumulate; fp64 re-score of the candidates from the f32 rows"
             entry["roofline"]["kernel"] = "scan_kernel (bf16 mirror)"
             entry["roofline"]["note"] = ("bytes_per_launch are the mirror's: the fp32 rows (%d bytes) are not read by the scan"
@@ -324,10 +326,16 @@ def rank_main(args, world: int) -> None:
                     "avg_launch_ms": avg_s * 1e3, "launches_timed": launches,
                     "row_bytes_per_launch": bytes_per_launch, "row_read_gbs_if_read_once": gbs,
                 }
+                if dtype == "f32" and products == 1 and opts.get("bf16_mirror") != "0":
+                    # these passes read the bf16 mirror of the fp32 rows
+                    entry["roofline"]["row_bytes_per_launch"] = mirror_bytes
+                    entry["roofline"]["row_read_gbs_if_read_once"] = mirror_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
                 if nq < 128:
                     # less than one 128-query tile: the pass is bound by reading the rows once
-                    entry["roofline"].update({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                              "frac": gbs / HBM_PEAK_GBS, "bytes_per_launch": bytes_per_launch,
+                    rb = entry["roofline"]["row_bytes_per_launch"]
+                    g1 = entry["roofline"]["row_read_gbs_if_read_once"]
+                    entry["roofline"].update({"bound": "hbm", "achieved": g1, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                              "frac": g1 / HBM_PEAK_GBS, "bytes_per_launch": rb,
                                               "algorithmic_tflops": tf})
         # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE, runs of their own, gfx950
         # half-count correction applied); only known for configurations that were profiled with the

@@ -83,6 +83,20 @@ int vdb_shutdown(void);
  * type, two products per term; default 0: rounded once),
  * "gemm32s_threads" (workgroup shape of the 256-query tile: 512 = 8 waves over 256 rows (default),
  * 256 = 4 waves over 128 rows, two workgroups per CU).
+ * "gemm_pp" (1 = batches of more than 128 queries run on the 256 x 256-tile kernel that loads its
+ * operands straight into LDS (default); 0 = the converting kernel for every batch size),
+ * "gemm_pp_parts" (1 = the last pass of that kernel tightens its threshold after an eighth of the
+ * rows (default)).
+ * Store: "bf16_mirror" (1 = fp32 tables keep a bf16 copy of their rows, half of the table again in
+ * HBM, which the batched passes multiply from (default); 0 = no copy, rows are converted on the fly),
+ * "virtual_ranges" (1 = table arrays are reserved virtual ranges backed chunk by chunk as the table
+ * grows, so growth never copies (default); 0 = plain allocations, copied on growth),
+ * "scan_mirror" (1 = single queries over fp32 tables scan the bf16 mirror: half the bytes, the same
+ * exact answers through a wider certificate, more queries to the exact pass on tie-heavy data;
+ * default 0).  The three apply to tables created, and searches started, after the call.
+ * Exactness layer: "l2_row_bounds" (1 = L2 keys carry the error term of their own row, so rows of very
+ * large norm do not send other queries to the exact pass (default); 0 = table-wide norm bound),
+ * "force_exact" (1 = every query is answered by the exact pass; for measuring it).
  * Host calls: "coalesce_host" (1 = blocking vdb_search calls that arrive from other threads while one
  * is running are merged into one batched search, see vdb_search; default 1). */
 int vdb_set_option(const char* key, double value);

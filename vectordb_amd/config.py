@@ -13,6 +13,11 @@ in `raw` so that an existing file loads unchanged.
   engine_config.coalesce_searches (an addition, default true)  searches that arrive while another one
       is running are merged into one batched call (inside vdb_search; in front of the workers of the
       multi-GPU client: vectordb_amd/coalesce.py)
+  engine_config.scan_mirror (an addition, default false)  single queries over fp32 tables scan the bf16
+      mirror of the rows: half the bytes per query and the same exact answers (the certificate of the
+      fast pass widens by the rounding; tie-heavy data sends more queries to the exact pass)
+  engine_config.bf16_mirror (an addition, default true)  fp32 tables keep that mirror (half of the table
+      again in HBM); without it batched searches convert the fp32 rows on the fly, at half the speed
   gpu_resource_config.enable (:41)           must be true: there is no CPU engine
   gpu_resource_config.cache_capacity (:42)   GB of HBM the tables may occupy (0 = no cap)
   gpu_resource_config.search_resources (:43-44)  `gpuN` entries: the shard set; a process binds
@@ -38,6 +43,8 @@ class EngineConfig:
     use_blas_threshold: int = 2          # this engine's measured crossover; the file's value wins when present
     gpu_search_threshold: int = 1000
     coalesce_searches: bool = True
+    scan_mirror: bool = False
+    bf16_mirror: bool = True
     gpu_enable: bool = True
     cache_capacity_gb: float = 0.0
     search_resources: List[int] = field(default_factory=lambda: [0])
@@ -74,6 +81,10 @@ def parse_config(doc: Optional[Dict[str, Any]]) -> EngineConfig:
         cfg.gpu_search_threshold = int(eng["gpu_search_threshold"])
     if "coalesce_searches" in eng:
         cfg.coalesce_searches = bool(eng["coalesce_searches"])
+    if "scan_mirror" in eng:
+        cfg.scan_mirror = bool(eng["scan_mirror"])
+    if "bf16_mirror" in eng:
+        cfg.bf16_mirror = bool(eng["bf16_mirror"])
     if "enable" in gpu:
         cfg.gpu_enable = bool(gpu["enable"])
     if "cache_capacity" in gpu and gpu["cache_capacity"] is not None:

@@ -36,6 +36,8 @@ class Engine:
         check(self.lib.vdb_set_option(b"cache_capacity_gb", float(self.config.cache_capacity_gb)))
         check(self.lib.vdb_set_option(b"insert_buffer_size_gb", float(self.config.insert_buffer_size_gb)))
         check(self.lib.vdb_set_option(b"coalesce_host", 1.0 if self.config.coalesce_searches else 0.0))
+        check(self.lib.vdb_set_option(b"scan_mirror", 1.0 if self.config.scan_mirror else 0.0))
+        check(self.lib.vdb_set_option(b"bf16_mirror", 1.0 if self.config.bf16_mirror else 0.0))
 
     # ---- lifecycle
     def create_table(self, name: str, dim: int, metric: int = METRIC_IP, dtype: int = F32) -> None:
