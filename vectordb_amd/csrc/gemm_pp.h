@@ -11,7 +11,8 @@
 // L2 tables: Q16 holds -2q and the accumulators start at the row's squared norm, so that
 // acc = ||x||^2 - 2 x.q (smaller is better); the key handed on is -acc, as on every other path.
 //
-// Each wave owns 128 rows x 64 queries (4 x 2 blocks of v_mfma_f32_32x32x16).  LDS stage buffer:
+// Each wave owns 128 rows x 64 queries: 8 x 4 blocks of v_mfma_f32_16x16x32 (SHAPE 16, the shape in
+// use: higher sustained clock) or 4 x 2 blocks of v_mfma_f32_32x32x16 (SHAPE 32).  LDS stage buffer:
 // A tile [256 rows][32 k] then B tile [256 queries][32 k], 64-byte rows; the 16-byte chunk c of row r
 // sits in slot c ^ ((-(r >> 2)) & 3), which makes every ds_read_b128 fragment read conflict-free.
 // global_load_lds writes 1 KiB per wave-instruction linearly (16 rows x 64 bytes), so the swizzle is
@@ -21,7 +22,7 @@
 //   LOAD(s):  [epilogue of the tile that ended at s-1]  ds_read fragments of s;  issue loads of s+3
 //             into buffer (s+3)&3;  s_waitcnt vmcnt(N) leaving the loads of s+2, s+3 in flight (so
 //             this wave's part of s+1 has landed);  s_waitcnt lgkmcnt(0);  s_barrier
-//   COMP(s):  16 MFMAs;  s_barrier
+//   COMP(s):  32 MFMAs (SHAPE 16);  s_barrier
 // Waves 4-7 run one barrier behind waves 0-3.  A buffer is read in LOAD(s) only, one barrier after
 // every wave waited for its loads (read after write), and refilled in LOAD(s+1) of the next round,
 // at least one barrier after every wave retired its reads of it (write after read).
