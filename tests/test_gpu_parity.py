@@ -109,7 +109,7 @@ def test_search_parity_fp32_dims(engine, table_name, metric, d):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
-@pytest.mark.parametrize("d", [8, 128, 520, 768, 4100])
+@pytest.mark.parametrize("d", [8, 128, 300, 384, 520, 768, 4100])
 @pytest.mark.parametrize("metric", ["ip", "cosine", "l2"])
 def test_search_parity_16bit(engine, table_name, metric, d, dtype):
     n = 2000

@@ -238,7 +238,7 @@ void set_scan_tune(int nt, int waves, int blocks_per_cu, int contiguous) {
 template <int NCH> struct ScanUnroll { static constexpr int U = (NCH <= 1) ? 8 : (NCH <= 3) ? 4 : (NCH <= 6) ? 2 : 1; };
 
 // LPR lanes share one row per wave-instruction (64/LPR rows per instruction); a row takes NCH
-// such instructions (NCH > 1 only with LPR == 64).  Every load is unconditional: lanes past the
+// such instructions (three of 16 or 32 lanes for rows of 48 or 96 units).  Every load is unconditional: lanes past the
 // end of a row re-read its first 16 bytes against a zero query, rows past the end of the table
 // re-read the last row and are discarded.
 template <int DT, int LPR, int NCH, bool NT>
@@ -420,6 +420,11 @@ scan_kernel_generic(ScanParams p) {
 struct ScanShape { int lpr, nch; bool generic; };
 static ScanShape scan_shape(int m, int dt) {
     ScanShape s{64, 1, false};
+    // rows of three quarters of a power of two (768 16-bit or 384 fp32 elements: 96 units) take three
+    // instructions of half that many lanes: no lane re-reads the row's head, as a quarter of them would
+    // with the next power of two
+    if (m > 64 && m <= 96) { s.lpr = 32; s.nch = 3; return s; }
+    if (m > 32 && m <= 48) { s.lpr = 16; s.nch = 3; return s; }
     if (m <= 64) {
         int l = 1;
         while (l < m) l <<= 1;
@@ -470,6 +475,7 @@ static hipError_t launch_scan_dt(const ScanShape& s, dim3 grid, dim3 block, size
         VDB_SCAN_CASE(1, 1) VDB_SCAN_CASE(2, 1) VDB_SCAN_CASE(4, 1) VDB_SCAN_CASE(8, 1)
         VDB_SCAN_CASE(16, 1) VDB_SCAN_CASE(32, 1) VDB_SCAN_CASE(64, 1)
         VDB_SCAN_CASE(64, 2) VDB_SCAN_CASE(64, 3) VDB_SCAN_CASE(64, 4)
+        VDB_SCAN_CASE(32, 3) VDB_SCAN_CASE(16, 3)
         if constexpr (DT == VDB_F32) { VDB_SCAN_CASE(64, 6) VDB_SCAN_CASE(64, 8) }
     }
 #undef VDB_SCAN_CASE
