@@ -32,5 +32,10 @@ step "SQ counters, batch 1024 (b)"
 timeout -s KILL 240 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VALU \
     --output-format csv -d "$out/${tag}_sq_b_b1024" -o p -- \
     python3 bench.py --nq 1024 --steps 3 --warmup 1 --cpu-seconds 0 > "$out/${tag}_sq_b_b1024.json" 2> "$out/${tag}_sq_b_b1024.err" || exit 1
+step "kernel summary and FETCH_SIZE, scan over the bf16 mirror"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_mirror" -o p -- \
+    python3 bench.py --no-secondary --cpu-seconds 0 --opt scan_mirror=1 > "$out/${tag}_bench_mirror.json" 2> "$out/${tag}_bench_mirror.err" || exit 1
+timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/${tag}_pmc_mirror" -o p -- \
+    python3 bench.py --steps 5 --warmup 2 --no-secondary --cpu-seconds 0 --opt scan_mirror=1 > "$out/${tag}_pmc_mirror.json" 2> "$out/${tag}_pmc_mirror.err" || exit 1
 step done
 find "$out" -name '*.csv' -path "*${tag}_*" | sort
