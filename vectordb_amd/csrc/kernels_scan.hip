@@ -150,6 +150,57 @@ __device__ __forceinline__ double canon_score_dt(const char* row, const float* q
     return wave_tree_sum(acc);
 }
 
+// The same for R rows at once (the exact pass): every row's sum is formed exactly as above, but the loads of
+// all R rows of a round are in flight together, which is what keeps that pass near the memory's rate.
+template <int DT, int R>
+__device__ __forceinline__ void canon_score_rows(const char* const* row, const float* q, int d, bool l2, int lane, double* out) {
+#pragma clang fp contract(off)
+    constexpr int UL = 8;                              // elements per lane, row and round
+    double acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.0;
+    for (int j0 = lane; j0 < d; j0 += 64 * UL) {
+        float xv[R][UL], yv[UL];
+#pragma unroll
+        for (int u = 0; u < UL; ++u) {
+            const int j = j0 + 64 * u;
+            const int jc = j < d ? j : d - 1;
+            yv[u] = j < d ? q[jc] : 0.f;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float x;
+                if constexpr (DT == VDB_F32) x = ((const float*)row[r])[jc];
+                else if constexpr (DT == VDB_BF16) x = __uint_as_float((uint32_t)((const unsigned short*)row[r])[jc] << 16);
+                else x = f16_bits(((const unsigned short*)row[r])[jc]);
+                xv[r][u] = j < d ? x : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UL; ++u) {
+            const double y = (double)yv[u];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const double x = (double)xv[r][u];
+                if (l2) {
+                    const double df = __dsub_rn(x, y);
+                    acc[r] = __dadd_rn(acc[r], __dmul_rn(df, df));
+                } else {
+                    acc[r] = __dadd_rn(acc[r], __dmul_rn(x, y));
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) out[r] = wave_tree_sum(acc[r]);
+}
+
+template <int R>
+__device__ __forceinline__ void canon_score_rows_dt(const char* const* row, const float* q, int d, int dt, bool l2, int lane, double* out) {
+    if (dt == VDB_F32) canon_score_rows<VDB_F32, R>(row, q, d, l2, lane, out);
+    else if (dt == VDB_BF16) canon_score_rows<VDB_BF16, R>(row, q, d, l2, lane, out);
+    else canon_score_rows<VDB_F16, R>(row, q, d, l2, lane, out);
+}
+
 __device__ __forceinline__ double canon_score(const char* row, const float* q, int d, int dt,
                                               bool l2, int lane) {
     if (dt == VDB_F32) return canon_score_dt<VDB_F32>(row, q, d, l2, lane);
@@ -1151,13 +1202,26 @@ exact_scan_kernel(ExactParams p) {
         WaveSel sel;
         sel.init(S_all + (size_t)wave * p.C, T_all + (size_t)wave * p.C, p.C, p.K, lane);
         const long long TW = (long long)gridDim.x * W;
-        for (long long r = (long long)blockIdx.x * W + wave; r < p.t.n; r += TW) {
-            const double sc = canon_score(p.t.rows + (size_t)r * rowbytes, q, p.t.d, p.t.dt, l2, lane);
-            const float fs = (float)sc;
-            const float key = l2 ? -fs : fs;
-            const long long id = p.t.ids[r];
-            const bool pass = (lane == 0) && better(key, id, sel.thr_s, sel.thr_t);
-            sel.push(pass, key, id, lane);
+        constexpr int R = 4;                   // rows per wave and round
+        for (long long r0 = (long long)blockIdx.x * W + wave; r0 < p.t.n; r0 += TW * R) {
+            const char* rp[R];
+            long long id[R];
+            double sc[R];
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                const long long r = r0 + j * TW;
+                const long long rc = r < p.t.n ? r : p.t.n - 1;
+                rp[j] = p.t.rows + (size_t)rc * rowbytes;
+                id[j] = p.t.ids[rc];
+            }
+            canon_score_rows_dt<R>(rp, q, p.t.d, p.t.dt, l2, lane, sc);
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                const float fs = (float)sc[j];
+                const float key = l2 ? -fs : fs;
+                const bool pass = (lane == 0) && (r0 + j * TW < p.t.n) && better(key, id[j], sel.thr_s, sel.thr_t);
+                sel.push(pass, key, id[j], lane);
+            }
         }
         block_merge(sel, S_all, T_all, W, wave, lane);
         if (wave == 0) {
