@@ -25,7 +25,7 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 // METHOD 0: global_load_lds_dwordx4.  METHOD 1: global_load_dwordx4 + ds_write_b128.
 // Half of every stage comes from `stream` (each byte read once: HBM), half from `hot` (a buffer of
 // hot_bytes that every workgroup re-reads: L2), as the row and query operands of the GEMM do.
-template <int METHOD, int WAVES, int DEPTH>
+template <int METHOD, int WAVES, int DEPTH, int SEG = 0>
 __global__ void __launch_bounds__(WAVES * 64)
 fill_kernel(const char* __restrict__ stream, const char* __restrict__ hot, size_t hot_bytes, long stages,
             int stream_only, int share, unsigned* __restrict__ sink) {
@@ -46,7 +46,23 @@ fill_kernel(const char* __restrict__ stream, const char* __restrict__ hot, size_
             const size_t piece = (size_t)wave * PER + i;           // 1 KiB piece of the stage
             const char* src;
             if (stream_only) src = sbase + (size_t)s * STAGE + piece * 1024 + lane * 16;
-            else if (from_stream) src = sbase + (size_t)s * (STAGE / 2) + ((size_t)wave * (PER / 2) + i) * 1024 + lane * 16;
+            else if (from_stream && SEG == 0) src = sbase + (size_t)s * (STAGE / 2) + ((size_t)wave * (PER / 2) + i) * 1024 + lane * 16;
+            else if (from_stream) {
+                // row-major operand: rows of 1536 bytes, a tile of 256 rows is read SEG bytes per row and stage
+                // (24 * 64 / SEG stages per tile); a wave-instruction covers 1024 / SEG rows
+                // SEG 1128: 128 bytes per row and stage, fetched as two 64-byte instructions back to back
+                constexpr bool PAIR = SEG == 1128;
+                constexpr int SG = PAIR ? 128 : (SEG ? SEG : 64);
+                constexpr int LPS = PAIR ? 4 : SG / 16;              // lanes per row segment of an instruction
+                constexpr int RPS = (STAGE / 2) / SG;                // rows a stage covers (a tile has 256)
+                constexpr int BLK = 256 / RPS;                       // stages per SG-byte column of a tile
+                const size_t tile = (size_t)s / 24, sub = (size_t)s % 24;     // 24 stages of 16 KiB per tile
+                const size_t ks = sub / BLK, rowblock = sub % BLK;
+                const size_t pieces = (size_t)wave * (PER / 2) + i;  // of the 16 KiB operand half: 1 KiB each
+                const size_t row = PAIR ? rowblock * RPS + (pieces >> 1) * 16 + lane / LPS
+                                        : rowblock * RPS + pieces * (1024 / SG) + lane / LPS;
+                src = sbase + (tile * 256 + row) * 1536 + ks * SG + (PAIR ? (pieces & 1) * 64 : 0) + (lane % LPS) * 16;
+            }
             else src = hot + (((size_t)s * (STAGE / 2) + ((size_t)wave * (PER / 2) + (i - PER / 2)) * 1024) % hot_bytes) + lane * 16;
             char* dst = smem + buf * STAGE + piece * 1024;
             if constexpr (METHOD == 0) {
@@ -82,18 +98,18 @@ fill_kernel(const char* __restrict__ stream, const char* __restrict__ hot, size_
     if (acc == 0x12345678u) sink[0] = acc;
 }
 
-template <int METHOD, int WAVES, int DEPTH>
+template <int METHOD, int WAVES, int DEPTH, int SEG = 0>
 static void run(const char* name, const char* stream, size_t stream_bytes, const char* hot, size_t hot_bytes,
                 int blocks, int stream_only, int share, unsigned* sink, double clock_ghz) {
     const size_t per_block = stream_bytes / (blocks / share);
     const long stages = (long)(per_block / (stream_only ? STAGE : STAGE / 2)) / 12 * 12;
     const size_t lds = (size_t)DEPTH * STAGE;
-    CK(hipFuncSetAttribute((const void*)fill_kernel<METHOD, WAVES, DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CK(hipFuncSetAttribute((const void*)fill_kernel<METHOD, WAVES, DEPTH, SEG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float best = 1e30f;
     for (int r = 0; r < 4; ++r) {
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL((fill_kernel<METHOD, WAVES, DEPTH>), dim3(blocks), dim3(WAVES * 64), lds, 0, stream, hot, hot_bytes, stages, stream_only, share, sink);
+        hipLaunchKernelGGL((fill_kernel<METHOD, WAVES, DEPTH, SEG>), dim3(blocks), dim3(WAVES * 64), lds, 0, stream, hot, hot_bytes, stages, stream_only, share, sink);
         CK(hipGetLastError());
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -126,6 +142,14 @@ int main(int argc, char** argv) {
         run<1, 8, 3>("registers 8 waves 3 stages", stream, sb4, hot, hot_bytes, blocks, 0, 4, sink, ghz);
         run<1, 16, 3>("registers 16 waves 3 stages", stream, sb4, hot, hot_bytes, blocks, 0, 4, sink, ghz);
     }
+    // row-major row operand, one query tile (nothing shared): 64-byte and 128-byte row segments per stage
+    run<0, 8, 4, 64>("lds-dma 8w 4st, rows 64 B/stage", stream, stream_bytes, hot, hot_bytes, cus, 0, 1, sink, ghz);
+    run<0, 8, 4, 128>("lds-dma 8w 4st, rows 128 B/stage", stream, stream_bytes, hot, hot_bytes, cus, 0, 1, sink, ghz);
+    run<0, 8, 4, 256>("lds-dma 8w 4st, rows 256 B/stage", stream, stream_bytes, hot, hot_bytes, cus, 0, 1, sink, ghz);
+    run<0, 8, 4, 1128>("lds-dma 8w 4st, rows 2 x 64 B/stage", stream, stream_bytes, hot, hot_bytes, cus, 0, 1, sink, ghz);
+    run<0, 8, 4, 1128>("lds-dma 8w 4st, rows 2 x 64 B, share 4", stream, sb4, hot, hot_bytes, cus, 0, 4, sink, ghz);
+    run<0, 8, 4, 64>("lds-dma 8w 4st, rows 64 B, share 4", stream, sb4, hot, hot_bytes, cus, 0, 4, sink, ghz);
+    run<0, 8, 4, 128>("lds-dma 8w 4st, rows 128 B, share 4", stream, sb4, hot, hot_bytes, cus, 0, 4, sink, ghz);
     for (int so = 0; so < 2; ++so) {
         for (int blocks : {cus, cus / 2}) {
             run<0, 8, 4>("lds-dma  8 waves 4 stages", stream, stream_bytes, hot, hot_bytes, blocks, so, 1, sink, ghz);

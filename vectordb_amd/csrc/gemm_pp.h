@@ -425,4 +425,5 @@ gemm_pp_kernel(GemmPPParams p) {
     if (wm == 0) __builtin_amdgcn_s_barrier();     // matches the extra barrier of waves 4-7
 }
 
+
 }  // namespace vdb
