@@ -94,6 +94,11 @@ def test_config_reads_reference_style_file(tmp_path):
     with pytest.raises(ValueError):
         parse_config({"gpu_resource_config": {"search_resources": ["cpu0"]}})
     assert isinstance(parse_config(None), EngineConfig)
+    # the engine's own additions default to: merged callers on, bf16 mirror on, mirror scan off
+    d = parse_config(None)
+    assert d.coalesce_searches and d.bf16_mirror and not d.scan_mirror
+    e = parse_config({"engine_config": {"scan_mirror": True, "bf16_mirror": False, "coalesce_searches": False}})
+    assert e.scan_mirror and not e.bf16_mirror and not e.coalesce_searches
 
 
 def test_snapshot_file_names_stay_inside_primary_path():
