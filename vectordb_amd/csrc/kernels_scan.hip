@@ -286,6 +286,13 @@ void set_scan_tune(int nt, int waves, int blocks_per_cu, int contiguous) {
     g_tune.nt = nt; g_tune.waves = waves; g_tune.blocks_per_cu = blocks_per_cu; g_tune.contiguous = contiguous;
 }
 
+#ifdef VDB_SCAN_STAMPS
+// diagnostic build only (tools/scan_waves.py): per wave of the last scan, the time from its start to the end of
+// its rows (10 ns ticks) and where it ran
+__device__ unsigned int g_scan_wave_end[16384];
+__device__ unsigned int g_scan_wave_xcc[16384];
+#endif
+
 template <int NCH> struct ScanUnroll { static constexpr int U = (NCH <= 1) ? 8 : (NCH <= 3) ? 4 : (NCH <= 6) ? 2 : 1; };
 
 // LPR lanes share one row per wave-instruction (64/LPR rows per instruction); a row takes NCH
@@ -309,6 +316,9 @@ scan_kernel(ScanParams p) {
     const int grp = lane / LPR;
     const float* q = p.q + (size_t)blockIdx.y * p.dpad;
 
+#ifdef VDB_SCAN_STAMPS
+    const unsigned long long stamp0 = wall_clock64();
+#endif
     constexpr bool PK = DT == VDB_BF16;            // packed bf16 arithmetic (see dot_unit_pk)
     int   off[NCH];
     float qv[NCH][PK ? 1 : EPL];
@@ -380,6 +390,19 @@ scan_kernel(ScanParams p) {
         }
     }
 
+#ifdef VDB_SCAN_STAMPS
+    {
+        const unsigned long long stamp1 = wall_clock64();
+        const unsigned w = (unsigned)(blockIdx.x * W + wave);
+        if (lane == 0 && w < 16384 && blockIdx.y == 0) {
+            unsigned xcc, hwid;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            g_scan_wave_end[w] = (unsigned)(stamp1 - stamp0);
+            g_scan_wave_xcc[w] = (xcc & 0xf) | (hwid << 4);
+        }
+    }
+#endif
     // every wave hands over its own sorted list: no merge inside the block
     sel.compact(lane);
     {
@@ -1356,3 +1379,11 @@ hipError_t launch_merge_topk(int nparts, int64_t nq, int k, int metric,
 }
 
 }  // namespace vdb
+
+#ifdef VDB_SCAN_STAMPS
+extern "C" int vdb_debug_scan_waves(unsigned int* ends, unsigned int* xcc, int n) {
+    if (hipMemcpyFromSymbol(ends, HIP_SYMBOL(vdb::g_scan_wave_end), (size_t)n * 4) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(xcc, HIP_SYMBOL(vdb::g_scan_wave_xcc), (size_t)n * 4) != hipSuccess) return -1;
+    return 0;
+}
+#endif
