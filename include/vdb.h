@@ -92,7 +92,8 @@ int vdb_shutdown(void);
  * "virtual_ranges" (1 = table arrays are reserved virtual ranges backed chunk by chunk as the table
  * grows, so growth never copies (default); 0 = plain allocations, copied on growth),
  * "scan_mirror" (1 = single queries over fp32 tables scan the bf16 mirror: half the bytes, the same
- * exact answers through a wider certificate, more queries to the exact pass on tie-heavy data;
+ * exact answers through a wider certificate; a query it cannot certify is re-scanned over the fp32
+ * rows before anything goes to the exact pass ("scan_mirror_tier2", default 1, switches that off);
  * default 0).  The three apply to tables created, and searches started, after the call.
  * Exactness layer: "l2_row_bounds" (1 = L2 keys carry the error term of their own row, so rows of very
  * large norm do not send other queries to the exact pass (default); 0 = table-wide norm bound),

@@ -659,6 +659,37 @@ def test_single_queries_over_the_bf16_mirror_of_an_fp32_table(engine, table_name
         engine.set_option("use_blas_threshold", 2)
 
 
+def test_mirror_scan_falls_back_to_the_fp32_rows_before_the_exact_pass(engine, table_name):
+    """Four hundred rows along the query's direction whose lengths differ by 5e-5 each: the scores around
+    rank 10 are closer together than the rounding of the bf16 mirror (2e-3) but far apart for an fp32 scan.
+    The mirror scan cannot certify its answer; the second tier re-scans the fp32 rows for that query and
+    can, so no exact pass runs (with the tier switched off it does)."""
+    n, d = 50_000, 64
+    rng = np.random.default_rng(73)
+    u = rng.standard_normal(d).astype(np.float32)
+    u /= np.linalg.norm(u)
+    rows = (0.1 * cases.make_rows("synth", 73, n, d)).astype(np.float32)
+    for j in range(400):
+        rows[j * 7] = (np.float32(1.0) + np.float32(j) * np.float32(5e-5)) * u
+    ids = cases.make_ids("hash", 73, n)
+    q = np.stack([3.0 * u, u + 0.01 * rng.standard_normal(d).astype(np.float32)]).astype(np.float32)
+    stored = _load(engine, table_name, rows, ids, O.IP, _lib.F32)
+    engine.set_option("scan_mirror", 1)
+    engine.set_option("use_blas_threshold", 1000)
+    try:
+        exact = {}
+        for tier2 in (1, 0):
+            engine.set_option("scan_mirror_tier2", tier2)
+            before = engine.stats()
+            _check(engine, table_name, stored, ids, q, 10, O.IP)
+            exact[tier2] = engine.stats()[1] - before[1]
+        assert exact[1] == 0 and exact[0] == 2, exact
+    finally:
+        engine.set_option("scan_mirror", 0)
+        engine.set_option("scan_mirror_tier2", 1)
+        engine.set_option("use_blas_threshold", 2)
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("nq", [3, 40, 150])
 def test_l2_rows_with_heavy_tailed_norms_stay_on_the_fast_path(engine, table_name, nq, dtype):

@@ -220,7 +220,8 @@ __global__ void __launch_bounds__(64)
 prep_query_kernel(const float* __restrict__ q_raw, int d, int dpad, int metric,
                   float* __restrict__ qprep, QInfo* __restrict__ qinfo, int* __restrict__ need_exact) {
     const int lane = threadIdx.x;
-    if (blockIdx.x == 0 && lane == 0) need_exact[0] = 0;     // empty list of queries for the exact pass
+    // empty lists of flagged queries: the one the finalize step fills, and behind it the one of a second tier
+    if (blockIdx.x == 0 && lane == 0) { need_exact[0] = 0; need_exact[1 + gridDim.x] = 0; }
     const float* q = q_raw + (size_t)blockIdx.x * d;
     float* out = qprep + (size_t)blockIdx.x * dpad;
     double acc = 0.0;
@@ -272,6 +273,7 @@ struct ScanParams {
     float*       cand_h;    // [nq][G*W]: best key of each list, contiguous for the finalize kernel
     const float* floor;     // [nq] lower bound of the K-th best key per query, or null
     RowBound     rb;        // L2: error term added to every key (see RowBound)
+    const int*   only;      // null, or a list {count, query indices...}: row y of the grid scans for query only[1 + y]
 };
 
 // Launch tunables of the scan (set through vdb_set_option, defaults chosen by measurement).
@@ -314,7 +316,9 @@ scan_kernel(ScanParams p) {
     const int wave = threadIdx.x >> 6;
     const int lir = lane & (LPR - 1);
     const int grp = lane / LPR;
-    const float* q = p.q + (size_t)blockIdx.y * p.dpad;
+    int qy = blockIdx.y;
+    if (p.only) { if (qy >= p.only[0]) return; qy = p.only[1 + qy]; }
+    const float* q = p.q + (size_t)qy * p.dpad;
 
 #ifdef VDB_SCAN_STAMPS
     const unsigned long long stamp0 = wall_clock64();
@@ -349,7 +353,7 @@ scan_kernel(ScanParams p) {
 
     WaveSel sel;
     sel.init(S_all + (size_t)wave * p.C, T_all + (size_t)wave * p.C, p.C, p.K, lane,
-             p.floor ? p.floor[blockIdx.y] : neg_inf());
+             p.floor ? p.floor[qy] : neg_inf());
     const bool rbon = p.l2 && p.rb.qinfo != nullptr;
     const float ea = rbon ? p.rb.a : 0.f;
     const float es = rbon ? rowbound_s(p.rb, lane) : 0.f;
@@ -394,7 +398,7 @@ scan_kernel(ScanParams p) {
     {
         const unsigned long long stamp1 = wall_clock64();
         const unsigned w = (unsigned)(blockIdx.x * W + wave);
-        if (lane == 0 && w < 16384 && blockIdx.y == 0) {
+        if (lane == 0 && w < 16384 && qy == 0) {
             unsigned xcc, hwid;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
@@ -406,7 +410,7 @@ scan_kernel(ScanParams p) {
     // every wave hands over its own sorted list: no merge inside the block
     sel.compact(lane);
     {
-        const size_t o = (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * W + wave) * p.K;
+        const size_t o = (((size_t)qy * gridDim.x + blockIdx.x) * W + wave) * p.K;
         for (int i = lane; i < p.K; i += 64) { p.cand_s[o + i] = sel.s[i]; p.cand_t[o + i] = sel.t[i]; }
         if (lane == 0) p.cand_h[o / p.K] = sel.s[0];
     }
@@ -426,7 +430,9 @@ scan_kernel_generic(ScanParams p) {
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const float* q = p.q + (size_t)blockIdx.y * p.dpad;
+    int qy = blockIdx.y;
+    if (p.only) { if (qy >= p.only[0]) return; qy = p.only[1 + qy]; }
+    const float* q = p.q + (size_t)qy * p.dpad;
     const int nch = (p.m + 63) >> 6;
     // query staged as nch chunks of 64 units, zero beyond the row
     for (int i = threadIdx.x; i < nch * 64 * EPL; i += blockDim.x) qs[i] = (i < p.dpad) ? q[i] : 0.f;
@@ -434,7 +440,7 @@ scan_kernel_generic(ScanParams p) {
 
     WaveSel sel;
     sel.init(S_all + (size_t)wave * p.C, T_all + (size_t)wave * p.C, p.C, p.K, lane,
-             p.floor ? p.floor[blockIdx.y] : neg_inf());
+             p.floor ? p.floor[qy] : neg_inf());
     const bool rbon = p.l2 && p.rb.qinfo != nullptr;
     const float ea = rbon ? p.rb.a : 0.f;
     const float es = rbon ? rowbound_s(p.rb, lane) : 0.f;
@@ -484,7 +490,7 @@ scan_kernel_generic(ScanParams p) {
     // every wave hands over its own sorted list: no merge inside the block
     sel.compact(lane);
     {
-        const size_t o = (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * W + wave) * p.K;
+        const size_t o = (((size_t)qy * gridDim.x + blockIdx.x) * W + wave) * p.K;
         for (int i = lane; i < p.K; i += 64) { p.cand_s[o + i] = sel.s[i]; p.cand_t[o + i] = sel.t[i]; }
         if (lane == 0) p.cand_h[o / p.K] = sel.s[0];
     }
@@ -563,8 +569,9 @@ static hipError_t launch_scan_dt(const ScanShape& s, dim3 grid, dim3 block, size
 
 hipError_t launch_scan(const TableView& t, const float* qprep, int64_t nq, int dpad,
                        const SelGeom& g, int G, float* cand_s, long long* cand_t, float* cand_h,
-                       const float* floor, hipStream_t st) {
+                       const float* floor, const int* only, hipStream_t st) {
     ScanParams p;
+    p.only = only;
     p.rows = t.rows; p.n2 = t.n2; p.q = qprep; p.n = t.n; p.m = t.m; p.dpad = dpad;
     p.K = g.K; p.C = g.C; p.l2 = (t.metric == VDB_METRIC_L2) ? 1 : 0;
     p.rb = t.rb;
@@ -626,6 +633,7 @@ struct FinParams {
     float*           out_scores;
     int*             out_counts;
     int*             need_exact;
+    const int*       only;       // lists mode: null, or {count, query indices...}: block b works on query only[1 + b]
     long long*       counters;
     // flat mode: one unsorted candidate array per query (batched path)
     const int*       flat_cnt;   // [nq] candidates appended (may exceed flat_cap: the excess was lost)
@@ -759,7 +767,8 @@ finalize_kernel(FinParams p) {
     float*     VS   = RS + KR;                          // FIN_CAP survivor keys
     int*       VI   = (int*)(VS + FIN_CAP);             // FIN_CAP survivor positions
 
-    const int qi = blockIdx.x;
+    int qi = blockIdx.x;
+    if (p.only) { if (qi >= p.only[0]) return; qi = p.only[1 + qi]; }     // block-uniform
     const long long M = (long long)p.G * K;
     const size_t qoff = (size_t)qi * M;
     const float*     gs = p.cand_s + qoff;
@@ -973,7 +982,7 @@ finalize_kernel(FinParams p) {
             if (p.force_exact) cert = false;
             if (!cert) { const int pos = atomicAdd(&p.need_exact[0], 1); p.need_exact[1 + pos] = qi; }
             STAMP(5);
-            atomicAdd((unsigned long long*)&p.counters[0], 1ull);
+            if (!p.only) atomicAdd((unsigned long long*)&p.counters[0], 1ull);      // a second tier answers queries already counted
         }
     }
 }
@@ -1135,10 +1144,11 @@ hipError_t launch_finalize(const TableView& t, const float* qprep, const QInfo* 
                            int dpad, const SelGeom& g, int G, int k,
                            const float* cand_s, const long long* cand_t, const float* cand_h,
                            long long* out_ids, float* out_scores, int* out_counts,
-                           int* need_exact, long long* counters, const FlatBound& fb, hipStream_t st) {
+                           int* need_exact, long long* counters, const FlatBound& fb, const int* only, hipStream_t st) {
     FinParams p;
     p.t = t; p.q = qprep; p.qinfo = qinfo; p.dpad = dpad;
     p.K = g.K; p.C = g.C; p.G = G; p.k = k;
+    p.only = only;
     p.cand_s = cand_s; p.cand_t = cand_t; p.cand_h = cand_h;
     p.out_ids = out_ids; p.out_scores = out_scores; p.out_counts = out_counts;
     p.need_exact = need_exact; p.counters = counters;
@@ -1177,6 +1187,7 @@ hipError_t launch_finalize_flat(const TableView& t, const float* qprep, const QI
     FinParams p;
     p.t = t; p.q = qprep; p.qinfo = qinfo; p.dpad = dpad;
     p.K = g.K; p.C = g.C; p.G = 0; p.k = k;
+    p.only = nullptr;
     p.cand_s = cand_s; p.cand_t = cand_t; p.cand_h = nullptr;
     p.out_ids = out_ids; p.out_scores = out_scores; p.out_counts = out_counts;
     p.need_exact = need_exact; p.counters = counters;

@@ -114,6 +114,7 @@ struct Global {
     int tune_pp = 1;                     // batches over 128 queries run on the ping-pong kernel
     int force_exact = 0;                 // measurement: every query takes the exact pass
     int tune_pp_parts = 1;               // the last batched pass tightens its threshold after an eighth of the rows
+    int mirror_tier2 = 1;                // queries the mirror scan cannot certify are re-scanned over the fp32 rows
     int scan_mirror = 0;                 // single queries over fp32 tables scan the bf16 mirror
     int row_bounds = 1;                  // L2 keys carry their own row's error term (0: table-wide norm bound)
     int tune_nt = 1, tune_waves = 8, tune_bpc = 4, tune_contig = 1, tune_gemm = 1, tune_split_f16 = 0, tune_split_bf16 = 0, tune_sample = 1, tune_gemm32s = 2;
@@ -279,7 +280,9 @@ static int search_scan_path(const TableView& tv_in, const SelGeom& g, int dpad, 
     const bool mirror = G.scan_mirror != 0 && !ws.fixed && tv.dt == VDB_F32 && tv.rows16 != nullptr && tv.ld16 == dpad &&
                         g.K >= 3 * k;
     if (mirror) { tsc.rows = (const char*)tv.rows16; tsc.m = (int)(tv.ld16 / 8); tsc.dt = VDB_BF16; }
-    const int Gx = scan_grid(tsc, g, G.n_cu);
+    const int Gx1 = scan_grid(tsc, g, G.n_cu);
+    const int Gx2 = mirror ? scan_grid(tv, g, G.n_cu) : Gx1;      // second tier over the fp32 rows
+    const int Gx = Gx1 > Gx2 ? Gx1 : Gx2;                         // sizes the buffers
     const int64_t chunk = 256;
     const int64_t nqc = nq < chunk ? nq : chunk;
     int rc;
@@ -288,7 +291,7 @@ static int search_scan_path(const TableView& tv_in, const SelGeom& g, int dpad, 
     if ((rc = ensure(ws.cand_s, (size_t)nqc * Gx * g.W * g.K * sizeof(float), ws.last_stream, ws.fixed))) return rc;
     if ((rc = ensure(ws.cand_t, (size_t)nqc * Gx * g.W * g.K * sizeof(long long), ws.last_stream, ws.fixed))) return rc;
     if ((rc = ensure(ws.cand_h, (size_t)nqc * Gx * g.W * sizeof(float), ws.last_stream, ws.fixed))) return rc;
-    if ((rc = ensure(ws.need_exact, (size_t)(nqc + 1) * sizeof(int), ws.last_stream, ws.fixed))) return rc;
+    if ((rc = ensure(ws.need_exact, (size_t)(2 * nqc + 2) * sizeof(int), ws.last_stream, ws.fixed))) return rc;
     // Many short rows and a long candidate list: every wave would spend its first K*ln(rows/K)
     // rows filling and sorting its own list.  A scan of a small sample of the rows (1/256) first
     // gives the K-th best key of the sample, a lower bound of the K-th best key of the table; the
@@ -321,7 +324,7 @@ static int search_scan_path(const TableView& tv_in, const SelGeom& g, int dpad, 
         VDB_HIP(launch_prep_query(q_dev + (size_t)q0 * tv.d, nqi, tv.d, dpad, tv.metric, qprep, qinfo, ne, st));
         const float* floor = nullptr;
         if (sampled) {
-            VDB_HIP(launch_scan(tvs, qprep, nqi, dpad, g, Gs, cs, ct, (float*)ws.cand_h.p, nullptr, st));
+            VDB_HIP(launch_scan(tvs, qprep, nqi, dpad, g, Gs, cs, ct, (float*)ws.cand_h.p, nullptr, nullptr, st));
             VDB_HIP(launch_lists_floor(g, Gs * g.W, nqi, cs, ct, (const float*)ws.cand_h.p, (float*)ws.small.p, st));
             floor = (const float*)ws.small.p;
         }
@@ -339,7 +342,7 @@ static int search_scan_path(const TableView& tv_in, const SelGeom& g, int dpad, 
             }
             ProfScope prof;
             if (!ws.fixed && (rc = prof.begin(st))) return rc;
-            VDB_HIP(launch_scan(tsc, qprep, nqi, dpad, g, Gx, cs, ct, (float*)ws.cand_h.p, floor, st));
+            VDB_HIP(launch_scan(tsc, qprep, nqi, dpad, g, Gx1, cs, ct, (float*)ws.cand_h.p, floor, nullptr, st));
             if (!ws.fixed && (rc = prof.end(st))) return rc;
             if (ordered) {
                 const int slot = (G.chain_head + 1) % 16;
@@ -349,12 +352,27 @@ static int search_scan_path(const TableView& tv_in, const SelGeom& g, int dpad, 
                 G.chain_last = st;
             }
         }
-        VDB_HIP(launch_finalize(tv, qprep, qinfo, nqi, dpad, g, Gx * g.W, k, cs, ct, (const float*)ws.cand_h.p,
+        VDB_HIP(launch_finalize(tv, qprep, qinfo, nqi, dpad, g, Gx1 * g.W, k, cs, ct, (const float*)ws.cand_h.p,
                                 out_ids + (size_t)q0 * k, out_scores + (size_t)q0 * k, out_counts + q0,
-                                ne, G.d_counters, fb, st));
+                                ne, G.d_counters, fb, nullptr, st));
+        int* flagged = ne;
+        if (mirror && G.mirror_tier2) {
+            // second tier: the queries the mirror could not certify are scanned again over the fp32 rows (a
+            // launch whose other workgroups leave at once), with the narrow bound; what this cannot certify
+            // either goes on to the exact pass
+            int* ne2 = ne + 1 + nqi;
+            FlatBound fb2;
+            fb2.force_exact = G.force_exact;
+            if (tv.metric == VDB_METRIC_L2 && G.row_bounds) tv.rb = l2_row_bound(fb2, tv.d, qinfo, (int)nqi);
+            VDB_HIP(launch_scan(tv, qprep, nqi, dpad, g, Gx2, cs, ct, (float*)ws.cand_h.p, nullptr, ne, st));
+            VDB_HIP(launch_finalize(tv, qprep, qinfo, nqi, dpad, g, Gx2 * g.W, k, cs, ct, (const float*)ws.cand_h.p,
+                                    out_ids + (size_t)q0 * k, out_scores + (size_t)q0 * k, out_counts + q0,
+                                    ne2, G.d_counters, fb2, ne, st));
+            flagged = ne2;
+        }
         VDB_HIP(launch_exact(tv, qprep, nqi, dpad, g, Gx, k, cs, ct,
                              out_ids + (size_t)q0 * k, out_scores + (size_t)q0 * k, out_counts + q0,
-                             ne, G.d_counters, st));
+                             flagged, G.d_counters, st));
     }
     return VDB_OK;
 }
@@ -432,7 +450,7 @@ static int search_gemm_path(const TableView& tv_in, const SelGeom& g, int dpad, 
     if ((rc = ensure(ws.qinfo, (size_t)nqc * sizeof(QInfo), ws.last_stream))) return rc;
     if ((rc = ensure(ws.cand_s, slots * sizeof(float), ws.last_stream))) return rc;
     if ((rc = ensure(ws.cand_t, slots * sizeof(long long), ws.last_stream))) return rc;
-    if ((rc = ensure(ws.need_exact, (size_t)(nqc + 1) * sizeof(int), ws.last_stream))) return rc;
+    if ((rc = ensure(ws.need_exact, (size_t)(2 * nqc + 2) * sizeof(int), ws.last_stream))) return rc;
     if ((rc = ensure(ws.small, (size_t)nqc * 20, ws.last_stream))) return rc;
     if ((half || s32) && (rc = ensure(ws.q16, (size_t)nqc * qstride * 4, ws.last_stream))) return rc;
     if (use_pp && (rc = ensure(ws.qimg, pp_query_image_bytes((int)nqc, dpad), ws.last_stream))) return rc;
@@ -883,6 +901,7 @@ int vdb_set_option(const char* key, double value) {
     else if (k == "force_exact") G.force_exact = value != 0;
     else if (k == "gemm_pp_parts") G.tune_pp_parts = value != 0;
     else if (k == "scan_mirror") G.scan_mirror = value != 0;
+    else if (k == "scan_mirror_tier2") G.mirror_tier2 = value != 0;
     else if (k == "l2_row_bounds") G.row_bounds = value != 0;
     else if (k == "bf16_mirror") G.bf16_mirror = value != 0;
     else if (k == "virtual_ranges") G.use_vmm = value != 0;
@@ -1294,7 +1313,7 @@ int vdb_search_dev_noalloc(const char* name, int64_t nq, const float* queries_de
     const int Gx = tv.n > 0 ? scan_grid(tv, g, G.n_cu) : 1;
     const size_t lists = (size_t)nq * Gx * g.W;
     const size_t want[7] = {(size_t)nq * t->dpad * sizeof(float), (size_t)nq * sizeof(QInfo), lists * g.K * sizeof(float),
-                            lists * g.K * sizeof(long long), lists * sizeof(float), (size_t)(nq + 1) * sizeof(int),
+                            lists * g.K * sizeof(long long), lists * sizeof(float), (size_t)(2 * nq + 2) * sizeof(int),
                             (size_t)nq * sizeof(float)};
     if (nq > 256) return fail(VDB_EINVAL, "vdb_search_dev_noalloc takes at most 256 queries per call");
     Workspace ws;

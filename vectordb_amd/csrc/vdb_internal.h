@@ -82,8 +82,9 @@ hipError_t launch_read_bw(const void* buf, long long bytes, int nt, int blocks, 
                           unsigned int* sink, hipStream_t st);
 
 // ---- launchers (all asynchronous on `st`) -------------------------------------------------
-// Also empties the list of queries flagged for the exact pass: need_exact[0] = count,
-// need_exact[1..] = query indices (nq + 1 ints).
+// Also empties two lists of flagged queries, {count, query indices...} of nq + 1 ints each, one behind
+// the other at need_exact: the one the finalize step fills for the exact pass, and a second one for a
+// pass in between.  `only` arguments below take such a list and restrict a launch to its queries.
 hipError_t launch_prep_query(const float* q_raw, int64_t nq, int d, int dpad, int metric,
                              float* qprep, QInfo* qinfo, int* need_exact, hipStream_t st);
 
@@ -92,7 +93,7 @@ hipError_t launch_prep_query(const float* q_raw, int64_t nq, int d, int dpad, in
 int  scan_grid(const TableView& t, const SelGeom& g, int n_cu);
 hipError_t launch_scan(const TableView& t, const float* qprep, int64_t nq, int dpad,
                        const SelGeom& g, int G, float* cand_s, long long* cand_t, float* cand_h,
-                       const float* floor, hipStream_t st);
+                       const float* floor, const int* only, hipStream_t st);
 
 // Terms a fast pass adds to the plain fp32 scoring-error bound of the certificate.
 struct FlatBound {
@@ -110,7 +111,7 @@ hipError_t launch_finalize(const TableView& t, const float* qprep, const QInfo* 
                            int dpad, const SelGeom& g, int G, int k,
                            const float* cand_s, const long long* cand_t, const float* cand_h,
                            long long* out_ids, float* out_scores, int* out_counts,
-                           int* need_exact, long long* counters, const FlatBound& fb, hipStream_t st);
+                           int* need_exact, long long* counters, const FlatBound& fb, const int* only, hipStream_t st);
 
 // Same for the batched path: one unsorted candidate array of `cap` slots per query, `cnt[q]`
 // appended, every non-candidate row known to have a fast key <= tau[q].
