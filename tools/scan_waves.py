@@ -9,8 +9,9 @@ from vectordb_amd import _lib
 from vectordb_amd.engine import Engine
 eng = Engine(0); lib = eng.lib
 dev = torch.device("cuda:0"); s = torch.cuda.current_stream().cuda_stream
-rows, dim = 1_000_000, 768
-eng.create_table("t", dim, _lib.METRIC_IP, _lib.F32); eng.reserve("t", rows); eng.insert_synthetic("t", rows, seed=0, first_row=0)
+rows, dim = (int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000), (int(sys.argv[2]) if len(sys.argv) > 2 else 768)
+DT = _lib.BF16 if (len(sys.argv) > 3 and sys.argv[3] == 'bf16') else _lib.F32
+eng.create_table("t", dim, _lib.METRIC_IP, DT); eng.reserve("t", rows); eng.insert_synthetic("t", rows, seed=0, first_row=0)
 q = torch.empty((16, dim), dtype=torch.float32, device=dev); eng.synth_fill_dev(q.data_ptr(), 16, dim, seed=1, first_row=0, stream=s)
 ids = torch.empty((1, 10), dtype=torch.int64, device=dev); sc = torch.empty((1, 10), dtype=torch.float32, device=dev); cn = torch.empty((1,), dtype=torch.int32, device=dev)
 for i in range(8):
