@@ -273,7 +273,8 @@ static int search_scan_path(const TableView& tv_in, const SelGeom& g, int dpad, 
     // What the scan reads.  fp32 tables can be scanned on their bf16 mirror (option scan_mirror): half
     // the bytes; the rounding of the rows (2^-9 of ||x|| ||q||) goes into the certificate's bound, and
     // the candidates are re-scored from the fp32 rows as always, so the answer is the same or the
-    // query takes the exact pass.  Needs a mirror row as long as the prepared query (dim % 32 == 0).
+    // query is flagged: for a second scan over the fp32 rows below, and for the exact pass if that
+    // cannot certify it either.  Needs a mirror row as long as the prepared query (dim % 32 == 0).
     TableView tsc = tv;
     // The list must reach well past the k-th hit for the wider bound to certify (K = 32 for k = 10 does; K = 128 for
     // k = 100 sent two queries in three to the exact pass).
