@@ -99,7 +99,8 @@ int vdb_shutdown(void);
  * large norm do not send other queries to the exact pass (default); 0 = table-wide norm bound),
  * "force_exact" (1 = every query is answered by the exact pass; for measuring it).
  * Host calls: "coalesce_host" (1 = blocking vdb_search calls that arrive from other threads while one
- * is running are merged into one batched search, see vdb_search; default 1). */
+ * is running are merged into one batched search, see vdb_search, and vdb_insert calls of up to 256 rows
+ * into one append; default 1). */
 int vdb_set_option(const char* key, double value);
 const char* vdb_last_error(void);
 

@@ -316,6 +316,43 @@ def test_concurrent_searches_and_inserts(engine, table_name):
 
 
 # ------------------------------------------------------------------------------- device entry
+def test_concurrent_single_row_inserts_are_merged_and_each_gets_its_own_verdict(engine, table_name):
+    """Sixteen threads insert one row per call (the reference's /insert pattern, app.py:315-325); calls that
+    arrive together are appended in one launch.  Every tenth call of one thread carries a NaN: exactly those
+    calls fail, every other row is stored once, bit for bit what the oracle stores."""
+    d, per, nthreads = 96, 60, 16
+    rows = cases.make_rows("synth", 77, nthreads * per, d)
+    ids = np.arange(nthreads * per, dtype=np.int64) * 3 - 500
+    bad = set(range(5 * per, 6 * per, 10))                        # calls of thread 5
+    engine.create_table(table_name, d, O.COSINE, _lib.F32)
+    failed, errors = set(), []
+
+    def work(t):
+        for j in range(t * per, (t + 1) * per):
+            row = rows[j:j + 1].copy()
+            if j in bad:
+                row[0, 7] = np.nan
+            try:
+                engine.insert(table_name, row, ids[j:j + 1])
+            except _lib.VdbError as e:
+                (failed.add(j) if e.code == _lib.EINVAL else errors.append((j, e)))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(nthreads)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors and failed == bad
+    n = engine.count(table_name)
+    assert n == nthreads * per - len(bad)
+    got_rows, got_ids = engine.fetch_rows(table_name, 0, n)
+    order = np.argsort(got_ids)
+    keep = np.array([j for j in range(nthreads * per) if j not in bad])
+    assert np.array_equal(got_ids[order], ids[keep])
+    want = O.prepare_store(rows[keep], O.COSINE, _lib.F32)
+    assert np.array_equal(got_rows[order].view(np.uint32), want.view(np.uint32))
+
+
 def test_search_dev_and_shard_merge(engine):
     """Row-sharded search on one device: S logical shards, per-shard vdb_search_dev, then
     vdb_merge_topk_dev -- the same data path the multi-GPU host side drives over RCCL."""

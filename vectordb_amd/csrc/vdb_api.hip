@@ -1066,6 +1066,21 @@ static int insert_locked(Table& t, int64_t n, const float* rows, const long long
     return VDB_OK;
 }
 
+static int insert_into(Table& t, int64_t n, const float* rows, const long long* ids,
+                       bool host, bool synth, uint64_t seed, int64_t first_row, hipStream_t user_st) {
+    if (t.vmm) {
+        // searches keep running: nothing they read moves or changes
+        std::shared_lock<std::shared_mutex> tl(t.mu);
+        std::lock_guard<std::mutex> il(t.ins_mu);
+        if (t.dropped) return fail(VDB_ENOTFOUND, "table was dropped");
+        return insert_locked(t, n, rows, ids, host, synth, seed, first_row, user_st);
+    }
+    std::unique_lock<std::shared_mutex> tl(t.mu);
+    std::lock_guard<std::mutex> il(t.ins_mu);
+    if (t.dropped) return fail(VDB_ENOTFOUND, "table was dropped");
+    return insert_locked(t, n, rows, ids, host, synth, seed, first_row, user_st);
+}
+
 static int insert_common(const char* name, int64_t n, const float* rows, const long long* ids,
                          bool host, bool synth, uint64_t seed, int64_t first_row, hipStream_t user_st) {
     int rc = enter();
@@ -1075,21 +1090,62 @@ static int insert_common(const char* name, int64_t n, const float* rows, const l
     auto t = find_table(name);
     if (!t) return fail(VDB_ENOTFOUND, std::string("no such table: ") + name);
     if (n == 0) return VDB_OK;
-    if (t->vmm) {
-        // searches keep running: nothing they read moves or changes
-        std::shared_lock<std::shared_mutex> tl(t->mu);
-        std::lock_guard<std::mutex> il(t->ins_mu);
-        if (t->dropped) return fail(VDB_ENOTFOUND, "table was dropped");
-        return insert_locked(*t, n, rows, ids, host, synth, seed, first_row, user_st);
+    return insert_into(*t, n, rows, ids, host, synth, seed, first_row, user_st);
+}
+
+// Small host inserts that arrive from several threads at once are merged like blocking searches are:
+// the first caller appends at once, callers that arrive meanwhile wait, and the next one to get the
+// turn appends everything waiting for the same table in one copy and one launch (each caller's rows
+// stay together).  A merged append that is refused (a row that is not finite) is repeated caller by
+// caller, so that only the caller with the bad row sees the error.
+struct InsReq {
+    MergeKey       key;                  // (table, -1)
+    int64_t        weight = 0;           // = n
+    bool           done = false;         // guarded by the merger
+    std::shared_ptr<Table> t;
+    int64_t        n = 0;
+    const float*   rows = nullptr;
+    const long long* ids = nullptr;
+    int            rc = VDB_OK;
+    std::string    err;
+};
+
+static void insert_host_batch(std::vector<InsReq*>& batch) {
+    auto one = [](InsReq* r) {
+        r->rc = insert_into(*r->t, r->n, r->rows, r->ids, true, false, 0, 0, nullptr);
+        if (r->rc != VDB_OK) r->err = tl_error;
+    };
+    if (batch.size() == 1) { one(batch[0]); return; }
+    Table& t = *batch[0]->t;
+    int64_t total = 0;
+    for (InsReq* r : batch) total += r->n;
+    std::vector<float> rows((size_t)total * t.dim);
+    std::vector<long long> ids((size_t)total);
+    int64_t at = 0;
+    for (InsReq* r : batch) {
+        std::memcpy(rows.data() + (size_t)at * t.dim, r->rows, (size_t)r->n * t.dim * sizeof(float));
+        std::memcpy(ids.data() + at, r->ids, (size_t)r->n * sizeof(long long));
+        at += r->n;
     }
-    std::unique_lock<std::shared_mutex> tl(t->mu);
-    std::lock_guard<std::mutex> il(t->ins_mu);
-    if (t->dropped) return fail(VDB_ENOTFOUND, "table was dropped");
-    return insert_locked(*t, n, rows, ids, host, synth, seed, first_row, user_st);
+    const int rc = insert_into(t, total, rows.data(), ids.data(), true, false, 0, 0, nullptr);
+    if (rc == VDB_OK) { for (InsReq* r : batch) r->rc = VDB_OK; return; }
+    for (InsReq* r : batch) one(r);          // nothing was published: every caller gets its own verdict
 }
 
 int vdb_insert(const char* name, int64_t n, const float* rows, const int64_t* ids) {
-    return insert_common(name, n, rows, (const long long*)ids, true, false, 0, 0, nullptr);
+    if (!G.coalesce_host || n < 1 || n > 256 || !name || !rows || !ids)
+        return insert_common(name, n, rows, (const long long*)ids, true, false, 0, 0, nullptr);
+    int rc = enter();
+    if (rc) return rc;
+    InsReq req;
+    req.t = find_table(name);
+    if (!req.t) return fail(VDB_ENOTFOUND, std::string("no such table: ") + name);
+    req.n = n; req.rows = rows; req.ids = (const long long*)ids;
+    req.key = MergeKey(req.t.get(), -1);
+    req.weight = n;
+    static CallMerger<InsReq> merger;
+    merger.submit(req, 4096, [](std::vector<InsReq*>& b) { insert_host_batch(b); });
+    return req.rc == VDB_OK ? VDB_OK : fail(req.rc, req.err);
 }
 
 int vdb_insert_dev(const char* name, int64_t n, const float* rows_dev, const int64_t* ids_dev, void* stream) {
