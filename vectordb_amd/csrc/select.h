@@ -62,22 +62,29 @@ struct WaveSel {
     __device__ void init(float* s_, long long* t_, int C_, int K_, int lane, float floor = neg_inf()) {
         s = s_; t = t_; C = C_; K = K_;
         for (int i = lane; i < C; i += 64) { s[i] = neg_inf(); t[i] = TAG_NONE; }
-        cnt = K;                       // K sentinels: any real row beats them
+        cnt = 0;                       // until K entries have come in, everything at or above the floor passes
         floor_s = floor;
         thr_s = floor; thr_t = TAG_NONE;
         lds_wave_sync();
     }
 
-    // Sort the list, keep the K best, refresh the threshold.  Called by the whole wave.
+    // Sort the live entries, keep the K best, refresh the threshold.  Called by the whole wave.
+    // Only the smallest power of two that holds the live entries is sorted (a wave that a floor lets
+    // end with a handful of entries sorts 64 slots, not C); slots behind the live entries hold
+    // (-inf, TAG_NONE) afterwards, up to K at least: the first K slots are always a valid sorted list.
     __device__ void compact(int lane) {
         lds_wave_sync();
-        for (int i = cnt + lane; i < C; i += 64) { s[i] = neg_inf(); t[i] = TAG_NONE; }
+        int P = 64;
+        while (P < cnt) P <<= 1;                                   // cnt <= C, a power of two >= 128
+        for (int i = cnt + lane; i < P; i += 64) { s[i] = neg_inf(); t[i] = TAG_NONE; }
         lds_wave_sync();
-        wave_bitonic_sort(s, t, C, lane);
-        cnt = K;
-        thr_s = s[K - 1];
-        thr_t = t[K - 1];
-        if (floor_s > thr_s) { thr_s = floor_s; thr_t = TAG_NONE; }
+        wave_bitonic_sort(s, t, P, lane);
+        if (cnt >= K) {
+            cnt = K;
+            thr_s = s[K - 1];
+            thr_t = t[K - 1];
+            if (floor_s > thr_s) { thr_s = floor_s; thr_t = TAG_NONE; }
+        }
     }
 
     // Called by the whole wave; lanes with pass == true contribute (key, tag).
@@ -85,7 +92,7 @@ struct WaveSel {
         const unsigned long long m = __ballot(pass);
         if (m == 0ull) return;
         const int n = __popcll(m);
-        if (cnt + n > C) compact(lane);        // afterwards cnt == K and K + 64 <= C
+        if (cnt + n > C) compact(lane);        // afterwards cnt <= K and K + 64 <= C
         const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
         if (pass) { s[pos] = key; t[pos] = tag; }
         cnt += n;

@@ -304,7 +304,7 @@ static int search_scan_path(const TableView& tv_in, const SelGeom& g, int dpad, 
     if (mirror) fb.extra_rel += 1.96e-3;
     fb.force_exact = G.force_exact;
     const size_t rowbytes = (size_t)tsc.m * 16;
-    const bool sampled = g.K >= 64 && rowbytes <= 1024 && tv.n >= 262144 && G.tune_sample != 0;
+    const bool sampled = g.K >= 64 && rowbytes <= (size_t)(G.tune_sample > 1 ? G.tune_sample : 1024) && tv.n >= 262144 && G.tune_sample != 0;
     TableView tvs = tsc;
     int Gs = 0;
     if (sampled) {
@@ -891,7 +891,7 @@ int vdb_set_option(const char* key, double value) {
     else if (k == "scan_blocks_per_cu") { if (value < 0 || value > 32) return fail(VDB_EINVAL, "scan_blocks_per_cu not in [0,32]"); G.tune_bpc = (int)value; }
     else if (k == "scan_contiguous") G.tune_contig = value != 0;
     else if (k == "scan_serialize") { std::lock_guard<std::mutex> cl(G.chain_mu); G.scan_serialize = value != 0; }
-    else if (k == "scan_sample") G.tune_sample = value != 0;
+    else if (k == "scan_sample") G.tune_sample = (int)value;     // 0 off, 1 rows up to 1024 bytes, larger: that many bytes
     else if (k == "coalesce_host") G.coalesce_host = value != 0;
     else if (k == "gemm_path") G.tune_gemm = value != 0;
     else if (k == "gemm_split_f16") G.tune_split_f16 = value != 0;
