@@ -73,7 +73,8 @@ int vdb_shutdown(void);
  * "scan_waves", "scan_blocks_per_cu", "scan_contiguous"; "scan_serialize" (1 = scans issued on
  * different streams run one after the other, chained by events, while the short kernels around
  * them overlap; 0 = scans of different streams may overlap); "scan_sample" (1 = for long candidate
- * lists over short rows, a scan of 1/256 of the rows first supplies a threshold floor to the full scan).
+ * lists over short rows, a scan of 1/256 of the rows first supplies a threshold floor to the full scan;
+ * rows of up to 1024 bytes, or of up to the value given when it is larger than 1; 0 = never).
  * Batched path (all its passes run on the 16-bit matrix unit; the finalize step re-scores every
  * candidate within twice the error bound of the k-th best fast key, so a coarser pass costs
  * re-scoring, never exactness): "gemm_path" (0 sends every batch through the scan path),

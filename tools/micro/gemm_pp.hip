@@ -2,6 +2,7 @@
 //   gemm_pp check            small shapes against a plain reference kernel (all keys, then candidates)
 //   gemm_pp time [rows] [nq] [dim] [reps] [l2]
 #include "../../vectordb_amd/csrc/gemm_pp.h"
+#include "gemm_pp4.h"
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -44,7 +45,7 @@ __global__ void norms_kernel(const unsigned short* X, long long ldx, long long n
     n2[r] = a;
 }
 
-static int g_shape = 32, g_tiled = 1;
+static int g_shape = 32, g_tiled = 1, g_kernel = 8;       // g_kernel 4: the four-wave form (gemm_pp4.h)
 template <bool L2M, bool DENSE, int SHAPE, bool TILED>
 static void launch_v(const GemmPPParams& p, int gx, int qtiles) {
     const int lds = L2M ? PP_LDS_L2 : PP_LDS_IP;
@@ -53,8 +54,17 @@ static void launch_v(const GemmPPParams& p, int gx, int qtiles) {
     hipLaunchKernelGGL((gemm_pp_kernel<1, L2M, DENSE, SHAPE, TILED>), dim3(gx, qtiles), dim3(512), lds, 0, p);
     CK(hipGetLastError());
 }
+template <bool L2M, bool DENSE, bool TILED>
+static void launch_4(const GemmPPParams& p, int gx, int qtiles) {
+    const int lds = L2M ? PP_LDS_L2 : PP_LDS_IP;
+    static bool once = false;
+    if (!once) { CK(hipFuncSetAttribute((const void*)gemm_pp4_kernel<1, L2M, DENSE, TILED>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); once = true; }
+    hipLaunchKernelGGL((gemm_pp4_kernel<1, L2M, DENSE, TILED>), dim3(gx, qtiles), dim3(256), lds, 0, p);
+    CK(hipGetLastError());
+}
 template <bool L2M, bool DENSE>
 static void launch_d(const GemmPPParams& p, int gx, int qtiles) {
+    if (g_kernel == 4) { if (g_tiled) launch_4<L2M, DENSE, true>(p, gx, qtiles); else launch_4<L2M, DENSE, false>(p, gx, qtiles); return; }
     if (g_shape == 32) { if (g_tiled) launch_v<L2M, DENSE, 32, true>(p, gx, qtiles); else launch_v<L2M, DENSE, 32, false>(p, gx, qtiles); }
     else { if (g_tiled) launch_v<L2M, DENSE, 16, true>(p, gx, qtiles); else launch_v<L2M, DENSE, 16, false>(p, gx, qtiles); }
 }
@@ -81,6 +91,7 @@ static unsigned short* make_tiled(const unsigned short* X, long long ld, long lo
 }
 
 static int run_check(long long n, int nq, int K, int l2, long long tile_stride, int gx_force) {
+    if (g_kernel == 4 && (((K + 31) / 32) & 1)) { printf("check K=%d skipped: the four-wave kernel takes an even number of k-steps\n", K); return 0; }
     const long long ldx = K;
     const int qstride = (K + 31) / 32 * 32;
     unsigned short *X, *Q; float *n2, *thr, *dense, *ref, *cs; long long* ct; int *cnt, *lost;
@@ -205,7 +216,7 @@ static void run_time(long long n, int nq, int K, int reps, int l2) {
     CK(hipMemcpy(hcnt.data(), cnt, nq * 4, hipMemcpyDeviceToHost));
     long long ctot = 0; for (int v : hcnt) ctot += v;
     const double flops = 2.0 * n * K * nq;
-    printf("shape %d tiled %d ", g_shape, g_tiled); printf("time n=%lld nq=%d K=%d l2=%d grid %dx%d: best %.3f ms, mean %.3f ms -> %.1f TFLOP/s (mean %.1f), %.2f TB/s of rows; %lld candidates\n",
+    printf("shape %d tiled %d kernel %d ", g_shape, g_tiled, g_kernel); printf("time n=%lld nq=%d K=%d l2=%d grid %dx%d: best %.3f ms, mean %.3f ms -> %.1f TFLOP/s (mean %.1f), %.2f TB/s of rows; %lld candidates\n",
            n, nq, K, l2, gx, qtiles, best, sum / reps, flops / best / 1e9, flops / (sum / reps) / 1e9, (double)n * K * 2 / best / 1e9, ctot);
     (void)0;
 }
@@ -213,9 +224,10 @@ static void run_time(long long n, int nq, int K, int reps, int l2) {
 int main(int argc, char** argv) {
     if (getenv("PP_SHAPE")) g_shape = atoi(getenv("PP_SHAPE")) == 16 ? 16 : 32;
     if (getenv("PP_TILED")) g_tiled = atoi(getenv("PP_TILED"));
+    if (getenv("PP_KERNEL")) g_kernel = atoi(getenv("PP_KERNEL"));
     if (argc >= 2 && !strcmp(argv[1], "check")) {
         int rc = 0;
-        printf("MFMA shape %d tiled %d\n", g_shape, g_tiled);
+        printf("MFMA shape %d tiled %d kernel %d\n", g_shape, g_tiled, g_kernel);
         rc |= run_check(256, 256, 64, 0, 1, 1);
         rc |= run_check(1024, 256, 768, 0, 1, 2);
         rc |= run_check(3000, 300, 768, 0, 1, 8);
