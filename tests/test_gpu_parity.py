@@ -225,6 +225,33 @@ def test_duplicate_ids_and_extreme_ids(engine, table_name):
     _check(engine, table_name, stored, ids, q, 10, O.IP)
 
 
+@pytest.mark.parametrize("metric", ["ip", "l2"])
+def test_exact_pass_keeps_rows_that_repeat_a_score_and_an_id(engine, table_name, metric):
+    """The exact pass orders by (score, stored id); rows that agree in both are distinct entries of the
+    ranking, as in the fast path and in the oracle (option force_exact sends every query there).  Its lists
+    drop a row that ties with their K-th entry, which leaves the K best pairs what they are."""
+    m = {"ip": O.IP, "l2": O.L2}[metric]
+    d = 24
+    rows = cases.make_rows("synth", 5, 3000, d)
+    ids = cases.make_ids("hash", 5, 3000)
+    for j in range(1, 25):                       # 25 copies of row 100 under one id: more than k, spread over blocks
+        rows[100 + 97 * j] = rows[100]
+        ids[100 + 97 * j] = ids[100]
+    rows[7] = rows[8]
+    ids[7] = ids[8]
+    q = np.concatenate([rows[100:101], rows[7:8], rows[1:2]])
+    stored = _load(engine, table_name, rows, ids, m, O.F32)
+    engine.set_option("force_exact", 1)
+    try:
+        _, f0, _ = engine.stats()
+        _check(engine, table_name, stored, ids, q, 10, m)
+        _check(engine, table_name, stored, ids, q, 40, m)
+        _, f1, _ = engine.stats()
+        assert f1 - f0 >= 6
+    finally:
+        engine.set_option("force_exact", 0)
+
+
 # ------------------------------------------------------------------------------- edges
 def test_empty_table_and_zero_queries(engine, table_name):
     engine.create_table(table_name, 8, _lib.METRIC_IP, _lib.F32)
