@@ -195,7 +195,7 @@ gemm_pp_kernel(GemmPPParams p) {
         }
     };
     set_tile_src();
-    // Every call issues the same number of loads (stages past the end re-read the last one's
+    // Every call issues the same number of operand loads (stages past the end re-read the last one's
     // operands into a buffer nobody reads), so that the counted waits below hold on every path.
     auto issue_a = [&](int buf) __attribute__((always_inline)) {
         char* dst = pp_smem + buf * PP_STAGE + wave * 2048;
@@ -207,7 +207,9 @@ gemm_pp_kernel(GemmPPParams p) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) pp_glds16(asrc[i] + f_ks * PP_KS, dst + i * 1024);
         }
-        if constexpr (L2M) pp_glds4(nsrc, pp_smem + PP_N2OFF + buf * 1024 + (wave & 3) * 256);
+        // L2: the rows' norms travel with the first k-step of their tile only (one more load in one stage of
+        // nks: the counted waits below allow for none, which is the stricter side)
+        if constexpr (L2M) { if (f_ks == 0) pp_glds4(nsrc, pp_smem + PP_N2OFF + buf * 1024 + (wave & 3) * 256); }
     };
     auto issue_b = [&](int buf) __attribute__((always_inline)) {
         char* dst = pp_smem + buf * PP_STAGE + wave * 2048;
@@ -219,7 +221,7 @@ gemm_pp_kernel(GemmPPParams p) {
         }
     };
     auto issue = [&](int buf) __attribute__((always_inline)) { issue_a(buf); issue_b(buf); };
-    constexpr int NA = L2M ? 3 : 2, NB = 2;
+    constexpr int NA = 2, NB = 2;
     constexpr int WAITN = 2 * (NA + NB);
     issue(0); issue(1); issue(2);
     asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * (NA + NB)) : "memory");
