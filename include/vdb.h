@@ -198,7 +198,9 @@ int vdb_merge_records_dev(int nparts, int64_t nq, int k, int metric, const void*
                           void* stream);
 
 /* ---- measurement hooks (bench.py) ------------------------------------------------------------ */
-/* When enabled, every scan kernel launch is bracketed by HIP events on its stream. */
+/* on = 1: every launch of the dominant kernel (table scan, full batched pass) is bracketed by HIP
+ * events on its stream; on = n > 1: every n-th launch (a pair of timing events costs about 10 us
+ * between two kernels, which is several per cent of a scan over a short table); 0: off. */
 int vdb_prof_enable(int on);
 /* Synchronises the recorded events; returns summed scan-kernel milliseconds and launch count
  * since the last call, and resets both. */

@@ -124,7 +124,8 @@ struct Global {
     hipStream_t insert_stream = nullptr;
     // profiling
     std::atomic<long long> batched_queries{0};
-    std::atomic<int> prof_on{0};
+    std::atomic<int> prof_on{0};         // 0 off, n: every n-th launch is bracketed by events
+    std::atomic<unsigned> prof_seq{0};
     std::mutex prof_mu;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
@@ -240,7 +241,8 @@ struct ProfScope {
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
     bool on = false;
     int begin(hipStream_t st) {
-        on = G.prof_on.load() != 0;
+        const int every = G.prof_on.load();
+        on = every > 0 && (every == 1 || G.prof_seq.fetch_add(1) % (unsigned)every == 0);
         if (!on) return VDB_OK;
         {
             std::lock_guard<std::mutex> lk(G.prof_mu);
@@ -1582,7 +1584,8 @@ int vdb_debug_read(long long* out32) {
 #endif
 
 int vdb_prof_enable(int on) {
-    G.prof_on.store(on ? 1 : 0);
+    G.prof_on.store(on > 0 ? on : 0);
+    G.prof_seq.store(0);
     return VDB_OK;
 }
 

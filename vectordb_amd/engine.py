@@ -164,8 +164,9 @@ class Engine:
                                           C.c_void_p(stream)))
 
     # ---- measurement
-    def prof_enable(self, on: bool) -> None:
-        check(self.lib.vdb_prof_enable(1 if on else 0))
+    def prof_enable(self, on) -> None:
+        """False/0 off, True/1 every launch of the dominant kernel timed, n > 1 every n-th launch."""
+        check(self.lib.vdb_prof_enable(int(on)))
 
     def prof_read(self) -> Tuple[float, int]:
         ms, n = C.c_double(0.0), C.c_int64(0)
