@@ -106,3 +106,67 @@ def test_million_rows_against_numpy_on_a_sample(engine, table_name, nq):
             ref = float(row[0].astype(np.float64) @ q.astype(np.float64))
             assert abs(float(got_sc[qi, j]) - ref) <= RTOL * abs(ref) + 1e-12
         assert np.all(np.diff(got_sc[qi]) <= 0)
+
+
+@pytest.mark.parametrize("n,d,dtype,metric,k", [
+    (1_000_000, 768, "f32", "cosine", 10),        # second BASELINE configuration
+    (10_000_000, 768, "f32", "cosine", 10),       # the headline configuration
+    (12_500_000, 128, "bf16", "ip", 100),         # one shard of 8 of the fourth configuration
+    (10_000_000, 768, "f16", "l2", 10),           # rows and metric of the fifth configuration
+])
+def test_whole_table_scored_by_numpy(engine, table_name, n, d, dtype, metric, k):
+    """BASELINE's shapes at full size: numpy scores EVERY stored row in fp32 (`X @ q`; for L2
+    `|x|^2 - 2 X @ q + |q|^2`), re-scores its best 256 + 8k rows in fp64 from the definition, orders them
+    with np.lexsort, and the search has to return those ids (wherever numpy's neighbouring scores are
+    further apart than the tolerance) with scores within 1e-5 relative.  16-bit tables are compared on
+    the rows as stored (fetched back), so the same bar holds for them."""
+    m = {"cosine": _lib.METRIC_COSINE, "ip": _lib.METRIC_IP, "l2": _lib.METRIC_L2}[metric]
+    t = {"f32": _lib.F32, "bf16": _lib.BF16, "f16": _lib.F16}[dtype]
+    engine.create_table(table_name, d, m, t)
+    engine.reserve(table_name, n)
+    engine.insert_synthetic(table_name, n, seed=43, first_row=0)
+    x = np.empty((n, d), dtype=np.float32)
+    step = 500_000
+    for a in range(0, n, step):
+        rows, got = engine.fetch_rows(table_name, a, min(step, n - a))
+        assert got[0] == a and got[-1] == a + rows.shape[0] - 1
+        x[a:a + rows.shape[0]] = rows
+    ids = np.arange(n, dtype=np.int64)
+    rng = np.random.default_rng(5)
+    queries = rng.standard_normal((4, d)).astype(np.float32)
+    queries[1] = x[n // 3] * 2.0 + 0.02 * queries[1]             # a query with a near neighbour
+    rep = 65
+    batch_ids, batch_sc, _ = engine.search(table_name, np.repeat(queries, rep, axis=0), k)   # batched path, 260 queries
+    n2 = np.einsum("ij,ij->i", x, x) if metric == "l2" else None
+    ncand = 256 + 8 * k
+    for qi in range(queries.shape[0]):
+        one_ids, one_sc, cnt = engine.search(table_name, queries[qi:qi + 1], k)              # scan
+        assert int(cnt[0]) == k
+        assert np.array_equal(one_ids[0], batch_ids[qi * rep]) and np.array_equal(one_sc[0], batch_sc[qi * rep])
+        q = queries[qi] / np.linalg.norm(queries[qi]) if metric == "cosine" else queries[qi]
+        q64 = q.astype(np.float64)
+        s32 = x @ q
+        if metric == "l2":
+            s32 = n2 - 2.0 * s32 + np.float32(q @ q)
+            key32 = s32                                   # smaller is better
+        else:
+            key32 = -s32
+        cand = np.argpartition(key32, ncand)[:ncand]
+        # rows outside the candidates cannot reach the top k: numpy's own fp32 error is far below this gap
+        kc = np.sort(key32[cand])
+        assert kc[-1] - kc[k] > 2e-4 * np.abs(kc).max()
+        xc = x[cand].astype(np.float64)
+        s64 = ((xc - q64[None, :]) ** 2).sum(axis=1) if metric == "l2" else xc @ q64
+        order = np.lexsort((ids[cand], s64 if metric == "l2" else -s64))
+        top = order[:k + 1]
+        for j in range(k):
+            ref = s64[top[j]]
+            tol = RTOL * abs(ref)
+            gap_prev = abs(ref - s64[top[j - 1]]) if j > 0 else np.inf
+            gap_next = abs(ref - s64[top[j + 1]])
+            if min(gap_prev, gap_next) > 4 * tol:
+                assert int(one_ids[0, j]) == int(ids[cand[top[j]]]), (qi, j, one_ids[0], ids[cand[top[:k]]])
+            hit = np.nonzero(ids[cand] == one_ids[0, j])[0]
+            assert hit.size == 1, "a returned row is not among numpy's best"
+            assert abs(float(one_sc[0, j]) - s64[hit[0]]) <= RTOL * abs(s64[hit[0]]) + 1e-12
+    del x
