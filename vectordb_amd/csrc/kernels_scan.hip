@@ -268,6 +268,7 @@ struct ScanParams {
     int          K, C;
     int          l2;
     int          contiguous;
+    int          dynamic;   // the waves of a workgroup draw their steps from a counter in LDS
     float*       cand_s;    // [nq][G*W][K]: one sorted list per wave
     long long*   cand_t;
     float*       cand_h;    // [nq][G*W]: best key of each list, contiguous for the finalize kernel
@@ -282,10 +283,12 @@ struct ScanTune {
     int waves = 8;           // waves per block (upper bound; the candidate-list geometry may lower it)
     int blocks_per_cu = 4;   // grid cap in blocks per CU (two are resident, two queue behind them)
     int contiguous = 1;      // 1 = each wave scans one contiguous range instead of interleaving
+    int dynamic = 1;         // 1 = the waves of a workgroup share its steps out among themselves as they go
 };
 static ScanTune g_tune;
-void set_scan_tune(int nt, int waves, int blocks_per_cu, int contiguous) {
+void set_scan_tune(int nt, int waves, int blocks_per_cu, int contiguous, int dynamic) {
     g_tune.nt = nt; g_tune.waves = waves; g_tune.blocks_per_cu = blocks_per_cu; g_tune.contiguous = contiguous;
+    g_tune.dynamic = dynamic;
 }
 
 #ifdef VDB_SCAN_STAMPS
@@ -365,8 +368,27 @@ scan_kernel(ScanParams p) {
     const size_t rowbytes = (size_t)p.m * 16;
     const long long last = p.n - 1;
 
-    for (long long st = 0; st < nsteps; ++st) {
-        const long long base = p.contiguous ? (gw * nsteps + st) * RPS : (st * TW + gw) * RPS;
+    // The waves of a workgroup get through equal shares at different speeds (they end up to 50 us apart on a
+    // scan of half a millisecond), so the workgroup's steps are handed out as the waves come for them: a
+    // counter in LDS, one ds_add per step of U x NCH loads.  Which wave scores a row does not matter to the
+    // result (every row is scored once, by the same arithmetic); the workgroup's rows are those of the static split.
+    unsigned* const ticket = (unsigned*)(smem + (size_t)W * p.C * (sizeof(float) + sizeof(long long)));
+    if (p.dynamic) {
+        if (threadIdx.x == 0) *ticket = 0u;
+        __syncthreads();
+    }
+    const long long wsteps = nsteps * W;                     // steps of the whole workgroup
+    auto draw = [&]() __attribute__((always_inline)) -> long long {
+        unsigned t = 0;
+        if (lane == 0) t = atomicAdd(ticket, 1u);
+        return (long long)__builtin_amdgcn_readfirstlane(t);
+    };
+    long long tk = p.dynamic ? draw() : wave;                // step of the workgroup: tk = st * W + (wave slot)
+    while (tk < wsteps) {
+        const long long st = tk / W, sub = tk - st * W;
+        const long long base = (p.contiguous ? (p.dynamic ? (long long)blockIdx.x * wsteps + tk : gw * nsteps + st)
+                                             : st * TW + (long long)blockIdx.x * W + sub) * RPS;
+        const long long tk_next = p.dynamic ? draw() : tk + W;
         u32x4 x[U][NCH];
         float nn[U];
 #pragma unroll
@@ -392,6 +414,7 @@ scan_kernel(ScanParams p) {
             const bool pass = (r <= last) && (lir == 0) && better(key, r, sel.thr_s, sel.thr_t);
             sel.push(pass, key, r, lane);
         }
+        tk = tk_next;
     }
 
 #ifdef VDB_SCAN_STAMPS
@@ -581,7 +604,8 @@ hipError_t launch_scan(const TableView& t, const float* qprep, int64_t nq, int d
     p.cand_s = cand_s; p.cand_t = cand_t; p.cand_h = cand_h; p.floor = floor;
     const ScanShape s = scan_shape(t.m, t.dt);
     const dim3 grid((unsigned)G, (unsigned)nq), block((unsigned)g.W * 64);
-    const size_t lds = (size_t)g.W * g.C * (sizeof(float) + sizeof(long long));
+    const size_t lds = (size_t)g.W * g.C * (sizeof(float) + sizeof(long long)) + 16;      // lists + the step counter
+    p.dynamic = g_tune.dynamic;
     switch (t.dt) {
         case VDB_F32:  return launch_scan_dt<VDB_F32>(s, grid, block, lds, p, st);
         case VDB_BF16: return launch_scan_dt<VDB_BF16>(s, grid, block, lds, p, st);

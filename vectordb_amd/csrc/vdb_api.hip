@@ -117,7 +117,7 @@ struct Global {
     int mirror_tier2 = 1;                // queries the mirror scan cannot certify are re-scanned over the fp32 rows
     int scan_mirror = 0;                 // single queries over fp32 tables scan the bf16 mirror
     int row_bounds = 1;                  // L2 keys carry their own row's error term (0: table-wide norm bound)
-    int tune_nt = 1, tune_waves = 8, tune_bpc = 4, tune_contig = 1, tune_gemm = 1, tune_split_f16 = 0, tune_split_bf16 = 0, tune_sample = 1, tune_gemm32s = 2;
+    int tune_nt = 1, tune_waves = 8, tune_bpc = 4, tune_contig = 1, tune_dyn = 1, tune_gemm = 1, tune_split_f16 = 0, tune_split_bf16 = 0, tune_sample = 1, tune_gemm32s = 2;
     // host-insert staging (guarded by insert_mu)
     std::mutex insert_mu;
     DevBuf stage_rows, stage_ids;
@@ -892,6 +892,7 @@ int vdb_set_option(const char* key, double value) {
     else if (k == "scan_waves") { if (value < 0 || value > 16) return fail(VDB_EINVAL, "scan_waves not in [0,16]"); G.tune_waves = (int)value; }
     else if (k == "scan_blocks_per_cu") { if (value < 0 || value > 32) return fail(VDB_EINVAL, "scan_blocks_per_cu not in [0,32]"); G.tune_bpc = (int)value; }
     else if (k == "scan_contiguous") G.tune_contig = value != 0;
+    else if (k == "scan_dynamic") G.tune_dyn = value != 0;
     else if (k == "scan_serialize") { std::lock_guard<std::mutex> cl(G.chain_mu); G.scan_serialize = value != 0; }
     else if (k == "scan_sample") G.tune_sample = (int)value;     // 0 off, 1 rows up to 1024 bytes, larger: that many bytes
     else if (k == "coalesce_host") G.coalesce_host = value != 0;
@@ -909,7 +910,7 @@ int vdb_set_option(const char* key, double value) {
     else if (k == "bf16_mirror") G.bf16_mirror = value != 0;
     else if (k == "virtual_ranges") G.use_vmm = value != 0;
     else return fail(VDB_EINVAL, "unknown option: " + k);
-    set_scan_tune(G.tune_nt, G.tune_waves, G.tune_bpc, G.tune_contig);
+    set_scan_tune(G.tune_nt, G.tune_waves, G.tune_bpc, G.tune_contig, G.tune_dyn);
     return VDB_OK;
 }
 

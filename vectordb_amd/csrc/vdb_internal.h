@@ -77,7 +77,7 @@ struct SearchScratch {
     long long* counters;    // [2]: queries, exact fallbacks (library-wide, not per scratch)
 };
 
-void set_scan_tune(int nt, int waves, int blocks_per_cu, int contiguous);
+void set_scan_tune(int nt, int waves, int blocks_per_cu, int contiguous, int dynamic);
 hipError_t launch_read_bw(const void* buf, long long bytes, int nt, int blocks, int threads,
                           unsigned int* sink, hipStream_t st);
 
