@@ -218,6 +218,23 @@ static void run_time(long long n, int nq, int K, int reps, int l2) {
     const double flops = 2.0 * n * K * nq;
     printf("shape %d tiled %d kernel %d ", g_shape, g_tiled, g_kernel); printf("time n=%lld nq=%d K=%d l2=%d grid %dx%d: best %.3f ms, mean %.3f ms -> %.1f TFLOP/s (mean %.1f), %.2f TB/s of rows; %lld candidates\n",
            n, nq, K, l2, gx, qtiles, best, sum / reps, flops / best / 1e9, flops / (sum / reps) / 1e9, (double)n * K * 2 / best / 1e9, ctot);
+#ifdef PP_STAMPS
+    {
+        std::vector<unsigned> h(4096);
+        CK(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_pp_end), 4096 * 4));
+        const int nb = gx * qtiles;
+        std::vector<double> e(nb);
+        for (int i = 0; i < nb; ++i) e[i] = h[i] / 100.0;
+        std::vector<double> srt(e); std::sort(srt.begin(), srt.end());
+        printf("workgroup run times (us): min %.0f p10 %.0f median %.0f p90 %.0f max %.0f\n", srt[0], srt[nb / 10], srt[nb / 2], srt[nb * 9 / 10], srt[nb - 1]);
+        for (int x = 0; x < 8; ++x) {
+            std::vector<double> g;
+            for (int i = 0; i < nb; ++i) if ((i % gx) % 8 == x) g.push_back(e[i]);
+            std::sort(g.begin(), g.end());
+            printf("  blockIdx.x %% 8 == %d: %zu workgroups, min %.0f median %.0f max %.0f\n", x, g.size(), g[0], g[g.size() / 2], g.back());
+        }
+    }
+#endif
     (void)0;
 }
 
