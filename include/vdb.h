@@ -74,7 +74,9 @@ int vdb_shutdown(void);
  * different streams run one after the other, chained by events, while the short kernels around
  * them overlap; 0 = scans of different streams may overlap); "scan_sample" (1 = for long candidate
  * lists over short rows, a scan of 1/256 of the rows first supplies a threshold floor to the full scan;
- * rows of up to 1024 bytes, or of up to the value given when it is larger than 1; 0 = never).
+ * rows of up to 1024 bytes, or of up to the value given when it is larger than 1; 0 = never);
+ * "scan_dynamic" (1 = the waves of a scan workgroup draw their steps from a counter in LDS (default);
+ * 0 = every wave scans a fixed share).
  * Batched path (all its passes run on the 16-bit matrix unit; the finalize step re-scores every
  * candidate within twice the error bound of the k-th best fast key, so a coarser pass costs
  * re-scoring, never exactness): "gemm_path" (0 sends every batch through the scan path),

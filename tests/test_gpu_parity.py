@@ -622,6 +622,36 @@ def test_queries_in_flight_on_several_streams(engine, table_name, ordered):
         assert np.array_equal(got_sc[qi].view(np.uint32), ws.view(np.uint32))
 
 
+@pytest.mark.parametrize("n,d,dtype,metric,k", [
+    (100_003, 768, "f32", "cosine", 10),      # three loads per row and lane
+    (250_001, 128, "bf16", "ip", 100),        # four rows per wave instruction, long lists
+    (77_777, 200, "f16", "l2", 10),           # ragged row length
+    (5_000, 1000, "f32", "ip", 10),           # fewer steps than waves: most draws come back empty
+    (60_001, 2500, "f32", "l2", 10),          # the generic kernel (no step counter) beside the others
+])
+def test_scan_step_counter_parity(engine, table_name, n, d, dtype, metric, k):
+    """The waves of a scan workgroup draw their steps from a counter in LDS, or scan fixed shares: every row is
+    scored exactly once either way, so both settings return the oracle's answer, bit for bit, whatever the
+    table's size leaves for the last step."""
+    rows = cases.make_rows("synth", 77, n, d)
+    ids = cases.make_ids("hash", 77, n)
+    q = cases.make_queries("synth", 77, 3, d, rows)
+    m = cases.METRICS[metric]
+    stored = _load(engine, table_name, rows, ids, m, cases.DTYPES[dtype])
+    engine.set_option("gemm_path", 0)           # three queries would otherwise go to the batched path
+    try:
+        _check(engine, table_name, stored, ids, q, k, m)
+        dynamic = engine.search(table_name, q, k)
+        engine.set_option("scan_dynamic", 0)
+        _check(engine, table_name, stored, ids, q, k, m)
+        fixed = engine.search(table_name, q, k)
+    finally:
+        engine.set_option("scan_dynamic", 1)
+        engine.set_option("gemm_path", 1)
+    for a, b in zip(dynamic, fixed):
+        assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("metric,dtype,kind", [("ip", "f32", "synth"), ("l2", "bf16", "synth"),
                                                ("cosine", "f16", "synth"), ("ip", "f32", "ties")])
 def test_sampled_floor_scan_parity(engine, table_name, metric, dtype, kind):
