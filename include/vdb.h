@@ -76,7 +76,8 @@ int vdb_shutdown(void);
  * lists over short rows, a scan of 1/256 of the rows first supplies a threshold floor to the full scan;
  * rows of up to 1024 bytes, or of up to the value given when it is larger than 1; 0 = never);
  * "scan_dynamic" (1 = the waves of a scan workgroup draw their steps from a counter in LDS (default);
- * 0 = every wave scans a fixed share).
+ * 0 = every wave scans a fixed share); "scan_short_gb" (tables below this many GB are scanned by one resident
+ * round of workgroups whose waves advance side by side; default 28).
  * Batched path (all its passes run on the 16-bit matrix unit; the finalize step re-scores every
  * candidate within twice the error bound of the k-th best fast key, so a coarser pass costs
  * re-scoring, never exactness): "gemm_path" (0 sends every batch through the scan path),

@@ -284,12 +284,14 @@ struct ScanTune {
     int blocks_per_cu = 4;   // grid cap in blocks per CU (two are resident, two queue behind them)
     int contiguous = 1;      // 1 = each wave scans one contiguous range instead of interleaving
     int dynamic = 1;         // 1 = the waves of a workgroup share its steps out among themselves as they go
+    double short_bytes = 2.8e10;   // tables below this size: one resident round of blocks, waves side by side
 };
 static ScanTune g_tune;
 void set_scan_tune(int nt, int waves, int blocks_per_cu, int contiguous, int dynamic) {
     g_tune.nt = nt; g_tune.waves = waves; g_tune.blocks_per_cu = blocks_per_cu; g_tune.contiguous = contiguous;
     g_tune.dynamic = dynamic;
 }
+void set_scan_short_bytes(double bytes) { g_tune.short_bytes = bytes; }
 
 #ifdef VDB_SCAN_STAMPS
 // diagnostic build only (tools/scan_waves.py): per wave of the last scan, the time from its start to the end of
@@ -555,12 +557,13 @@ int scan_grid(const TableView& t, const SelGeom& g, int n_cu) {
     // LDS and the 1024-thread bound admit one 16-wave block per CU; smaller blocks pack more.
     long long cap = (long long)n_cu * (g.W >= 16 ? 1 : (16 / g.W));
     if (g_tune.blocks_per_cu > 0) {
-        // Tables that stream in about a millisecond or less do best with only the blocks that are
-        // resident at once (two of 8 waves per CU): a second round of blocks costs its start-up and
-        // the first round's tail again (1 M x 768 fp32: 78.8 -> 83.2 % of the HBM peak); long scans
+        // Tables of up to about 28 GB do best with only the blocks that are resident at once (two of
+        // 8 waves per CU): a second round of blocks costs its start-up and the first round's tail
+        // again (1 M x 768 fp32: 78.8 -> 83.2 % of the HBM peak; with the step counter 5 M x 768:
+        // 86.9 -> 88.1 %, 8.5 M: 87.2 -> 87.8 %, 10 M: even, 12 M: 87.2 against 87.6 %); longer scans
         // gain more from the finer balance of four blocks per CU.
         const double bytes = (double)t.n * t.m * 16.0;
-        cap = (long long)n_cu * (bytes < 8e9 && g_tune.blocks_per_cu > 2 ? 2 : g_tune.blocks_per_cu);
+        cap = (long long)n_cu * (bytes < g_tune.short_bytes && g_tune.blocks_per_cu > 2 ? 2 : g_tune.blocks_per_cu);
     }
     return (int)(need < cap ? need : cap);
 }
@@ -600,7 +603,7 @@ hipError_t launch_scan(const TableView& t, const float* qprep, int64_t nq, int d
     p.rb = t.rb;
     // each wave scans one contiguous range of a long table; over short ones the waves advance through the
     // table side by side, so that they all end together (1 M x 768 fp32: 83.3 -> 84.0 % of the HBM peak)
-    p.contiguous = g_tune.contiguous && (double)t.n * t.m * 16.0 >= 8e9;
+    p.contiguous = g_tune.contiguous && (double)t.n * t.m * 16.0 >= g_tune.short_bytes;
     p.cand_s = cand_s; p.cand_t = cand_t; p.cand_h = cand_h; p.floor = floor;
     const ScanShape s = scan_shape(t.m, t.dt);
     const dim3 grid((unsigned)G, (unsigned)nq), block((unsigned)g.W * 64);

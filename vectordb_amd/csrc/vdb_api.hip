@@ -893,6 +893,7 @@ int vdb_set_option(const char* key, double value) {
     else if (k == "scan_blocks_per_cu") { if (value < 0 || value > 32) return fail(VDB_EINVAL, "scan_blocks_per_cu not in [0,32]"); G.tune_bpc = (int)value; }
     else if (k == "scan_contiguous") G.tune_contig = value != 0;
     else if (k == "scan_dynamic") G.tune_dyn = value != 0;
+    else if (k == "scan_short_gb") { if (value < 0) return fail(VDB_EINVAL, "scan_short_gb < 0"); set_scan_short_bytes(value * 1e9); }
     else if (k == "scan_serialize") { std::lock_guard<std::mutex> cl(G.chain_mu); G.scan_serialize = value != 0; }
     else if (k == "scan_sample") G.tune_sample = (int)value;     // 0 off, 1 rows up to 1024 bytes, larger: that many bytes
     else if (k == "coalesce_host") G.coalesce_host = value != 0;
