@@ -413,7 +413,7 @@ def rank_main(args, world: int) -> None:
             eng.set_option("scan_mirror", 0)
         # batch 1024 on the same table (MFMA GEMM + fused top-k)
         # (the matrix-unit passes of a process get faster over their first eight or so launches, 10.8 -> 10.05 ms for
-        # the seven-eighths launch in profiles/r2_f_bench_batch1024_gemm_pp_dispatches.csv, hence the longer warm-up)
+        # the seven-eighths launch in the per-dispatch trace of this command, hence the longer warm-up)
         secondary.append(run_workload(table, args.rows, n_local, 768, "f32", "cosine", 10, 1024, 10, 6, 1, latency=False))
         drop_and_settle(table, n_local * 768 * 6)
         other(20_000_000, 768, "f16", "l2", 10, 256, 10, 6, "20M of the 125M rows one GPU holds in the 1B x 768 fp16 L2 batch-256 configuration")

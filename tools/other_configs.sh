@@ -1,5 +1,5 @@
 #!/bin/bash
-# The other workload shapes behind DESIGN.md's table, one bench line each (GPU box, repository root):
+# The other workload shapes of the measurement table, one bench line each (GPU box, repository root):
 #   bash tools/other_configs.sh <out.jsonl>
 out=${1:-gpurun_out/other_configs.jsonl}
 : > "$out"
