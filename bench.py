@@ -388,12 +388,13 @@ def rank_main(args, world: int) -> None:
             eng.drop_table(name)
             time.sleep(min(3.0, 0.2 + nbytes / 2.5e10))
 
-        def other(rows, dim, dtype, mname, k, nq, steps, warmup, note):
+        def other(rows, dim, dtype, mname, k, nq, steps, warmup, note, n_streams=None):
             name = "bench_%s_%d" % (dtype, rows)
             eng.create_table(name, dim, METRICS[mname], DTYPES[dtype][0])
             eng.reserve(name, rows)
             eng.insert_synthetic(name, rows, seed=0, first_row=0)
-            e = run_workload(name, rows, rows, dim, dtype, mname, k, nq, steps, warmup, args.streams, latency=False)
+            e = run_workload(name, rows, rows, dim, dtype, mname, k, nq, steps, warmup,
+                             args.streams if n_streams is None else n_streams, latency=False)
             e["note"] = note
             secondary.append(e)
             drop_and_settle(name, rows * dim * DTYPES[dtype][1])
@@ -402,6 +403,10 @@ def rank_main(args, world: int) -> None:
         # lower clock for a while, which costs a scan of half a millisecond several per cent
         other(1_000_000, 768, "f32", "cosine", 10, 1, 1000, 100, "1M x 768 fp32 single query")
         other(12_500_000, 128, "bf16", "ip", 100, 1, 1000, 100, "one shard of 8 of the 100M x 128 bf16 top-100 configuration")
+        # what one GPU of eight does per query of the headline workload (--gpus 8 shards the 10M rows): without the
+        # all-gather and the merge, on three streams as the sharded path runs them
+        other(1_250_000, 768, "f32", "cosine", 10, 1, 1000, 100,
+              "one shard of 8 of the headline table (local part of a --gpus 8 step: no collective, no merge)", n_streams=3)
         # the headline workload with option scan_mirror: the scan reads the bf16 mirror of the rows (half the
         # bytes), the certificate's bound widens by the rounding, results are the same exact ones
         eng.set_option("scan_mirror", 1)
