@@ -1255,16 +1255,28 @@ exact_scan_kernel(ExactParams p) {
     long long* T_all = (long long*)(smem + (size_t)W * p.C * sizeof(float));
     const bool l2 = p.t.metric == VDB_METRIC_L2;
     const size_t rowbytes = (size_t)p.t.m * 16;
+    unsigned* const ticket = (unsigned*)(smem + (size_t)W * p.C * 12);
     const int nflag = p.need_exact[0];
     for (int f = blockIdx.y; f < nflag; f += gridDim.y) {
         const int qi = p.need_exact[1 + f];
         const float* q = p.q + (size_t)qi * p.dpad;
         __syncthreads();                       // the previous query's lists have been written out
+        if (threadIdx.x == 0) *ticket = 0u;
+        __syncthreads();
         WaveSel sel;
         sel.init(S_all + (size_t)wave * p.C, T_all + (size_t)wave * p.C, p.C, p.K, lane);
         const long long TW = (long long)gridDim.x * W;
         constexpr int R = 4;                   // rows per wave and round
-        for (long long r0 = (long long)blockIdx.x * W + wave; r0 < p.t.n; r0 += TW * R) {
+        // the rounds of the workgroup (W per TW * R rows) are drawn from a counter in LDS, as in the scan: the
+        // waves of a workgroup get through their rows at different speeds
+        const long long wrounds = (p.t.n + TW * R - 1) / (TW * R) * W;
+        while (true) {
+            unsigned tk = 0;
+            if (lane == 0) tk = atomicAdd(ticket, 1u);
+            tk = __builtin_amdgcn_readfirstlane(tk);
+            if ((long long)tk >= wrounds) break;
+            const long long r0 = (long long)(tk / W) * TW * R + (long long)blockIdx.x * W + (tk % W);
+            if (r0 >= p.t.n) continue;
             const char* rp[R];
             long long id[R];
             double sc[R];
@@ -1347,7 +1359,7 @@ hipError_t launch_exact(const TableView& t, const float* qprep, int64_t nq, int 
     p.need_exact = need_exact; p.counters = counters; p.G = G;
     const size_t lds = (size_t)g.W * g.C * 12;
     const unsigned gy = (unsigned)(nq < 8 ? nq : 8);
-    hipLaunchKernelGGL(exact_scan_kernel, dim3((unsigned)G, gy), dim3((unsigned)g.W * 64), lds, st, p);
+    hipLaunchKernelGGL(exact_scan_kernel, dim3((unsigned)G, gy), dim3((unsigned)g.W * 64), lds + 16, st, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const unsigned gf = (unsigned)(nq < 64 ? nq : 64);
