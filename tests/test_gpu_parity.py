@@ -627,7 +627,9 @@ def test_queries_in_flight_on_several_streams(engine, table_name, ordered):
     (250_001, 128, "bf16", "ip", 100),        # four rows per wave instruction, long lists
     (77_777, 200, "f16", "l2", 10),           # ragged row length
     (5_000, 1000, "f32", "ip", 10),           # fewer steps than waves: most draws come back empty
-    (60_001, 2500, "f32", "l2", 10),          # the generic kernel (no step counter) beside the others
+    (60_001, 2500, "f32", "l2", 10),          # the generic kernel: three chunks of four rows in flight
+    (30_001, 4100, "bf16", "cosine", 10),     # the generic kernel over 16-bit rows: two chunks in flight, ragged last chunk
+    (20_000, 3072, "f16", "l2", 10),          # the generic kernel, whole chunks
 ])
 def test_scan_step_counter_parity(engine, table_name, n, d, dtype, metric, k):
     """The waves of a scan workgroup draw their steps from a counter in LDS, or scan fixed shares: every row is

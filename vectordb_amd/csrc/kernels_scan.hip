@@ -476,9 +476,25 @@ scan_kernel_generic(ScanParams p) {
     const size_t rowbytes = (size_t)p.m * 16;
     const long long last = p.n - 1;
 
-    for (long long st = 0; st < nsteps; ++st) {
-        const long long base = (st * TW + gw) * U;
-        float acc[U];
+    // steps of the workgroup drawn from a counter in LDS, as in scan_kernel (the counter sits behind the query)
+    unsigned* const ticket = (unsigned*)(qs + (size_t)nch * 64 * EPL);
+    if (p.dynamic) {
+        if (threadIdx.x == 0) *ticket = 0u;
+        __syncthreads();
+    }
+    const long long wsteps = nsteps * W;
+    auto draw = [&]() __attribute__((always_inline)) -> long long {
+        unsigned t = 0;
+        if (lane == 0) t = atomicAdd(ticket, 1u);
+        return (long long)__builtin_amdgcn_readfirstlane(t);
+    };
+    long long tk = p.dynamic ? draw() : wave;
+    while (tk < wsteps) {
+        const long long st = tk / W, sub = tk - st * W;
+        const long long base = (p.contiguous ? (p.dynamic ? (long long)blockIdx.x * wsteps + tk : gw * nsteps + st)
+                                             : st * TW + (long long)blockIdx.x * W + sub) * U;
+        const long long tk_next = p.dynamic ? draw() : tk + W;
+        float acc[U], nn[U];
         const char* ptr[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -486,30 +502,40 @@ scan_kernel_generic(ScanParams p) {
             const long long rc = r < last ? r : last;
             ptr[u] = p.rows + (size_t)rc * rowbytes;
             acc[u] = 0.f;
+            nn[u] = p.l2 ? p.n2[rc] : 0.f;
         }
-        for (int c = 0; c < nch; ++c) {
-            const int unit = c * 64 + lane;
-            const int o = (unit < p.m) ? unit * 16 : 0;
-            float qv[EPL];
+        // three chunks of every row at a time: U x 3 loads in flight per wave (two for 16-bit rows, whose
+        // eight query values per chunk and conversions would not fit the registers otherwise)
+        constexpr int CG = DT == VDB_F32 ? 3 : 2;
+        for (int c = 0; c < nch; c += CG) {
+            float qv[CG][EPL];
+            u32x4 x[CG][U];
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) qv[e] = qs[unit * EPL + e];
-            u32x4 x[U];
+            for (int j = 0; j < CG; ++j) {
+                const int unit = (c + j) * 64 + lane;
+                const bool live = (c + j) < nch;                    // chunks past the row: first unit again, zero query
+                const int o = (live && unit < p.m) ? unit * 16 : 0;
 #pragma unroll
-            for (int u = 0; u < U; ++u) x[u] = load16<true>(ptr[u] + o);
+                for (int e = 0; e < EPL; ++e) qv[j][e] = live ? qs[unit * EPL + e] : 0.f;
 #pragma unroll
-            for (int u = 0; u < U; ++u) acc[u] = dot_unit<DT>(x[u], qv, acc[u]);
+                for (int u = 0; u < U; ++u) x[j][u] = load16<true>(ptr[u] + o);
+            }
+#pragma unroll
+            for (int j = 0; j < CG; ++j)
+#pragma unroll
+                for (int u = 0; u < U; ++u) acc[u] = dot_unit<DT>(x[j][u], qv[j], acc[u]);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             float a = acc[u];
             a = group_sum<64>(a);
             const long long r = base + u;
-            const long long rc = r < last ? r : last;
             float key = a;
-            if (p.l2) { const float nn = p.n2[rc]; key = 2.f * a - (rbon ? rowbound_adj(nn, ea, es) : nn); }
+            if (p.l2) key = 2.f * a - (rbon ? rowbound_adj(nn[u], ea, es) : nn[u]);
             const bool pass = (r <= last) && (lane == 0) && better(key, r, sel.thr_s, sel.thr_t);
             sel.push(pass, key, r, lane);
         }
+        tk = tk_next;
     }
 
     // every wave hands over its own sorted list: no merge inside the block
