@@ -74,7 +74,7 @@ int vdb_shutdown(void);
  * different streams run one after the other, chained by events, while the short kernels around
  * them overlap; 0 = scans of different streams may overlap); "scan_sample" (1 = for long candidate
  * lists over short rows, a scan of 1/256 of the rows first supplies a threshold floor to the full scan;
- * rows of up to 1024 bytes, or of up to the value given when it is larger than 1; 0 = never);
+ * rows of up to 4096 bytes, or of up to the value given when it is larger than 1; 0 = never);
  * "scan_dynamic" (1 = the waves of a scan workgroup draw their steps from a counter in LDS (default);
  * 0 = every wave scans a fixed share); "scan_short_gb" (tables below this many GB are scanned by one resident
  * round of workgroups whose waves advance side by side; default 28).

@@ -654,12 +654,13 @@ def test_scan_step_counter_parity(engine, table_name, n, d, dtype, metric, k):
         assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("metric,dtype,kind", [("ip", "f32", "synth"), ("l2", "bf16", "synth"),
-                                               ("cosine", "f16", "synth"), ("ip", "f32", "ties")])
-def test_sampled_floor_scan_parity(engine, table_name, metric, dtype, kind):
-    """Short rows, long candidate lists (k = 100) and enough rows: the scan starts from a floor taken
+@pytest.mark.parametrize("metric,dtype,kind,d", [("ip", "f32", "synth", 64), ("l2", "bf16", "synth", 64),
+                                                 ("cosine", "f16", "synth", 64), ("ip", "f32", "ties", 64),
+                                                 ("cosine", "f32", "synth", 768)])
+def test_sampled_floor_scan_parity(engine, table_name, metric, dtype, kind, d):
+    """Rows of up to 4 KiB, long candidate lists (k = 100) and enough rows: the scan starts from a floor taken
     from a sample of the rows.  Exact results with it, and the same results without it."""
-    n, d, k = 300_000, 64, 100
+    n, k = 300_000, 100
     rows = cases.make_rows(kind, 57, n, d)
     ids = cases.make_ids("hash", 57, n)
     q = cases.make_queries(kind, 57, 5, d, rows)

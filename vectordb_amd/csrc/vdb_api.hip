@@ -306,7 +306,7 @@ static int search_scan_path(const TableView& tv_in, const SelGeom& g, int dpad, 
     if (mirror) fb.extra_rel += 1.96e-3;
     fb.force_exact = G.force_exact;
     const size_t rowbytes = (size_t)tsc.m * 16;
-    const bool sampled = g.K >= 64 && rowbytes <= (size_t)(G.tune_sample > 1 ? G.tune_sample : 1024) && tv.n >= 262144 && G.tune_sample != 0;
+    const bool sampled = g.K >= 64 && rowbytes <= (size_t)(G.tune_sample > 1 ? G.tune_sample : 4096) && tv.n >= 262144 && G.tune_sample != 0;
     TableView tvs = tsc;
     int Gs = 0;
     if (sampled) {
