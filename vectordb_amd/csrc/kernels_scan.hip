@@ -590,6 +590,9 @@ int scan_grid(const TableView& t, const SelGeom& g, int n_cu) {
         // gain more from the finer balance of four blocks per CU.
         const double bytes = (double)t.n * t.m * 16.0;
         cap = (long long)n_cu * (bytes < g_tune.short_bytes && g_tune.blocks_per_cu > 2 ? 2 : g_tune.blocks_per_cu);
+        // blocks of four to seven waves (candidate lists of 512 to 1024 entries, 48 KiB of lists per block):
+        // three such blocks are resident per CU, and that one round is launched
+        if (g.W >= 4 && g.W < 8) cap = (long long)n_cu * 3;
     }
     return (int)(need < cap ? need : cap);
 }

@@ -228,6 +228,26 @@ SelGeom sel_geom(int k) {
     return g;
 }
 
+// Lists of the scan itself: a scanning wave never merges two lists (it hands its own over), so its list
+// needs room for K entries and one wave step of appends, not for two lists as the merges of the exact
+// pass do.  Same K; for K of 160 to 640 a smaller list and more waves per workgroup (k = 256: 8 waves instead of 4).
+static SelGeom scan_geom(const SelGeom& g, int max_waves) {
+    SelGeom s = g;
+    s.C = 64;
+    while (s.C < g.K + 64) s.C <<= 1;
+    if (s.C > g.C) s.C = g.C;
+    int w = 4096 / s.C;
+    if (w > 16) w = 16;
+    if (w < 1) w = 1;
+    // longer lists keep the common geometry: more lists per query would cost the finalize step more than the
+    // scan gains (its bound from the list heads lets everything through once K comes near the number of
+    // heads it ranks: 1 M x 768 at k = 800 fell from 680 to 380 QPS)
+    if (w < 4 || g.K > 640) return g;
+    if (max_waves > 0 && max_waves < w) w = max_waves;
+    s.W = w;
+    return s;
+}
+
 // ------------------------------------------------------------------------------ tiny kernels
 __global__ void fill_empty_kernel(long long* ids, float* scores, int* counts, long long nq, int k, int l2) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -272,6 +292,7 @@ static int search_scan_path(const TableView& tv_in, const SelGeom& g, int dpad, 
                             int k, long long* out_ids, float* out_scores, int* out_counts,
                             hipStream_t st, Workspace& ws) {
     TableView tv = tv_in;
+    const SelGeom gs = scan_geom(g, G.tune_waves);        // the scan's lists; g stays the geometry of the exact pass
     // What the scan reads.  fp32 tables can be scanned on their bf16 mirror (option scan_mirror): half
     // the bytes; the rounding of the rows (2^-9 of ||x|| ||q||) goes into the certificate's bound, and
     // the candidates are re-scored from the fp32 rows as always, so the answer is the same or the
@@ -283,17 +304,19 @@ static int search_scan_path(const TableView& tv_in, const SelGeom& g, int dpad, 
     const bool mirror = G.scan_mirror != 0 && !ws.fixed && tv.dt == VDB_F32 && tv.rows16 != nullptr && tv.ld16 == dpad &&
                         g.K >= 3 * k;
     if (mirror) { tsc.rows = (const char*)tv.rows16; tsc.m = (int)(tv.ld16 / 8); tsc.dt = VDB_BF16; }
-    const int Gx1 = scan_grid(tsc, g, G.n_cu);
-    const int Gx2 = mirror ? scan_grid(tv, g, G.n_cu) : Gx1;      // second tier over the fp32 rows
-    const int Gx = Gx1 > Gx2 ? Gx1 : Gx2;                         // sizes the buffers
+    const int Gx1 = scan_grid(tsc, gs, G.n_cu);
+    const int Gx2 = mirror ? scan_grid(tv, gs, G.n_cu) : Gx1;     // second tier over the fp32 rows
+    const int Gxe = scan_grid(tv, g, G.n_cu);                     // grid of the exact pass (one K-list per workgroup)
+    // lists per query the buffers hold: one per scanning wave, or one per workgroup of the exact pass
+    const size_t lists = (size_t)(Gx1 > Gx2 ? Gx1 : Gx2) * gs.W > (size_t)Gxe ? (size_t)(Gx1 > Gx2 ? Gx1 : Gx2) * gs.W : (size_t)Gxe;
     const int64_t chunk = 256;
     const int64_t nqc = nq < chunk ? nq : chunk;
     int rc;
     if ((rc = ensure(ws.qprep, (size_t)nqc * dpad * sizeof(float), ws.last_stream, ws.fixed))) return rc;
     if ((rc = ensure(ws.qinfo, (size_t)nqc * sizeof(QInfo), ws.last_stream, ws.fixed))) return rc;
-    if ((rc = ensure(ws.cand_s, (size_t)nqc * Gx * g.W * g.K * sizeof(float), ws.last_stream, ws.fixed))) return rc;
-    if ((rc = ensure(ws.cand_t, (size_t)nqc * Gx * g.W * g.K * sizeof(long long), ws.last_stream, ws.fixed))) return rc;
-    if ((rc = ensure(ws.cand_h, (size_t)nqc * Gx * g.W * sizeof(float), ws.last_stream, ws.fixed))) return rc;
+    if ((rc = ensure(ws.cand_s, (size_t)nqc * lists * g.K * sizeof(float), ws.last_stream, ws.fixed))) return rc;
+    if ((rc = ensure(ws.cand_t, (size_t)nqc * lists * g.K * sizeof(long long), ws.last_stream, ws.fixed))) return rc;
+    if ((rc = ensure(ws.cand_h, (size_t)nqc * lists * sizeof(float), ws.last_stream, ws.fixed))) return rc;
     if ((rc = ensure(ws.need_exact, (size_t)(2 * nqc + 2) * sizeof(int), ws.last_stream, ws.fixed))) return rc;
     // Many short rows and a long candidate list: every wave would spend its first K*ln(rows/K)
     // rows filling and sorting its own list.  A scan of a small sample of the rows (1/256) first
@@ -311,7 +334,7 @@ static int search_scan_path(const TableView& tv_in, const SelGeom& g, int dpad, 
     int Gs = 0;
     if (sampled) {
         tvs.n = tv.n / 256 > 4LL * g.K ? tv.n / 256 : 4LL * g.K;
-        Gs = scan_grid(tvs, g, G.n_cu);
+        Gs = scan_grid(tvs, gs, G.n_cu);
         if (Gs > G.n_cu) Gs = G.n_cu;                                 // one block per CU is plenty for 0.4 % of the rows
         if ((rc = ensure(ws.small, (size_t)nqc * sizeof(float), ws.last_stream, ws.fixed))) return rc;
     }
@@ -327,8 +350,8 @@ static int search_scan_path(const TableView& tv_in, const SelGeom& g, int dpad, 
         VDB_HIP(launch_prep_query(q_dev + (size_t)q0 * tv.d, nqi, tv.d, dpad, tv.metric, qprep, qinfo, ne, st));
         const float* floor = nullptr;
         if (sampled) {
-            VDB_HIP(launch_scan(tvs, qprep, nqi, dpad, g, Gs, cs, ct, (float*)ws.cand_h.p, nullptr, nullptr, st));
-            VDB_HIP(launch_lists_floor(g, Gs * g.W, nqi, cs, ct, (const float*)ws.cand_h.p, (float*)ws.small.p, st));
+            VDB_HIP(launch_scan(tvs, qprep, nqi, dpad, gs, Gs, cs, ct, (float*)ws.cand_h.p, nullptr, nullptr, st));
+            VDB_HIP(launch_lists_floor(gs, Gs * gs.W, nqi, cs, ct, (const float*)ws.cand_h.p, (float*)ws.small.p, st));
             floor = (const float*)ws.small.p;
         }
         {
@@ -345,7 +368,7 @@ static int search_scan_path(const TableView& tv_in, const SelGeom& g, int dpad, 
             }
             ProfScope prof;
             if (!ws.fixed && (rc = prof.begin(st))) return rc;
-            VDB_HIP(launch_scan(tsc, qprep, nqi, dpad, g, Gx1, cs, ct, (float*)ws.cand_h.p, floor, nullptr, st));
+            VDB_HIP(launch_scan(tsc, qprep, nqi, dpad, gs, Gx1, cs, ct, (float*)ws.cand_h.p, floor, nullptr, st));
             if (!ws.fixed && (rc = prof.end(st))) return rc;
             if (ordered) {
                 const int slot = (G.chain_head + 1) % 16;
@@ -355,7 +378,7 @@ static int search_scan_path(const TableView& tv_in, const SelGeom& g, int dpad, 
                 G.chain_last = st;
             }
         }
-        VDB_HIP(launch_finalize(tv, qprep, qinfo, nqi, dpad, g, Gx1 * g.W, k, cs, ct, (const float*)ws.cand_h.p,
+        VDB_HIP(launch_finalize(tv, qprep, qinfo, nqi, dpad, gs, Gx1 * gs.W, k, cs, ct, (const float*)ws.cand_h.p,
                                 out_ids + (size_t)q0 * k, out_scores + (size_t)q0 * k, out_counts + q0,
                                 ne, G.d_counters, fb, nullptr, st));
         int* flagged = ne;
@@ -367,13 +390,13 @@ static int search_scan_path(const TableView& tv_in, const SelGeom& g, int dpad, 
             FlatBound fb2;
             fb2.force_exact = G.force_exact;
             if (tv.metric == VDB_METRIC_L2 && G.row_bounds) tv.rb = l2_row_bound(fb2, tv.d, qinfo, (int)nqi);
-            VDB_HIP(launch_scan(tv, qprep, nqi, dpad, g, Gx2, cs, ct, (float*)ws.cand_h.p, nullptr, ne, st));
-            VDB_HIP(launch_finalize(tv, qprep, qinfo, nqi, dpad, g, Gx2 * g.W, k, cs, ct, (const float*)ws.cand_h.p,
+            VDB_HIP(launch_scan(tv, qprep, nqi, dpad, gs, Gx2, cs, ct, (float*)ws.cand_h.p, nullptr, ne, st));
+            VDB_HIP(launch_finalize(tv, qprep, qinfo, nqi, dpad, gs, Gx2 * gs.W, k, cs, ct, (const float*)ws.cand_h.p,
                                     out_ids + (size_t)q0 * k, out_scores + (size_t)q0 * k, out_counts + q0,
                                     ne2, G.d_counters, fb2, ne, st));
             flagged = ne2;
         }
-        VDB_HIP(launch_exact(tv, qprep, nqi, dpad, g, Gx, k, cs, ct,
+        VDB_HIP(launch_exact(tv, qprep, nqi, dpad, g, Gxe, k, cs, ct,
                              out_ids + (size_t)q0 * k, out_scores + (size_t)q0 * k, out_counts + q0,
                              flagged, G.d_counters, st));
     }
@@ -1371,8 +1394,10 @@ int vdb_search_dev_noalloc(const char* name, int64_t nq, const float* queries_de
     tv.dt = t->dtype; tv.metric = t->metric;
     SelGeom g = sel_geom(k);
     if (G.tune_waves > 0 && G.tune_waves < g.W) g.W = G.tune_waves;
-    const int Gx = tv.n > 0 ? scan_grid(tv, g, G.n_cu) : 1;
-    const size_t lists = (size_t)nq * Gx * g.W;
+    const SelGeom gs = scan_geom(g, G.tune_waves);
+    const int Gx = tv.n > 0 ? scan_grid(tv, gs, G.n_cu) : 1;
+    const int Gxe = tv.n > 0 ? scan_grid(tv, g, G.n_cu) : 1;
+    const size_t lists = (size_t)nq * ((size_t)Gx * gs.W > (size_t)Gxe ? (size_t)Gx * gs.W : (size_t)Gxe);
     const size_t want[7] = {(size_t)nq * t->dpad * sizeof(float), (size_t)nq * sizeof(QInfo), lists * g.K * sizeof(float),
                             lists * g.K * sizeof(long long), lists * sizeof(float), (size_t)(2 * nq + 2) * sizeof(int),
                             (size_t)nq * sizeof(float)};
