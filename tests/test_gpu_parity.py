@@ -654,6 +654,25 @@ def test_scan_step_counter_parity(engine, table_name, n, d, dtype, metric, k):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("k,metric,dtype,kind", [(150, "ip", "f32", "synth"), (256, "l2", "f32", "synth"),
+                                                 (500, "cosine", "bf16", "synth"), (256, "ip", "f32", "ties"),
+                                                 (600, "l2", "f16", "synth"), (640, "ip", "f32", "synth")])
+def test_scan_with_lists_of_its_own_size(engine, table_name, k, metric, dtype, kind):
+    """Candidate lists of 160 to 640 entries: the scan keeps lists of K + 64 entries (more waves per workgroup)
+    while the exact pass, which merges lists, keeps its 2K; the tie-heavy case goes through both."""
+    n, d = 120_000, 96
+    rows = cases.make_rows(kind, 63, n, d)
+    ids = cases.make_ids("hash", 63, n)
+    q = cases.make_queries(kind, 63, 3, d, rows)
+    m = cases.METRICS[metric]
+    stored = _load(engine, table_name, rows, ids, m, cases.DTYPES[dtype])
+    engine.set_option("gemm_path", 0)
+    try:
+        _check(engine, table_name, stored, ids, q, k, m)
+    finally:
+        engine.set_option("gemm_path", 1)
+
+
 @pytest.mark.parametrize("metric,dtype,kind,d", [("ip", "f32", "synth", 64), ("l2", "bf16", "synth", 64),
                                                  ("cosine", "f16", "synth", 64), ("ip", "f32", "ties", 64),
                                                  ("cosine", "f32", "synth", 768)])
