@@ -656,10 +656,13 @@ def test_scan_step_counter_parity(engine, table_name, n, d, dtype, metric, k):
 
 @pytest.mark.parametrize("k,metric,dtype,kind", [(150, "ip", "f32", "synth"), (256, "l2", "f32", "synth"),
                                                  (500, "cosine", "bf16", "synth"), (256, "ip", "f32", "ties"),
-                                                 (600, "l2", "f16", "synth"), (640, "ip", "f32", "synth")])
+                                                 (600, "l2", "f16", "synth"), (640, "ip", "f32", "synth"),
+                                                 (800, "cosine", "f32", "synth"), (1000, "l2", "f32", "synth"),
+                                                 (1024, "ip", "bf16", "ties")])
 def test_scan_with_lists_of_its_own_size(engine, table_name, k, metric, dtype, kind):
-    """Candidate lists of 160 to 640 entries: the scan keeps lists of K + 64 entries (more waves per workgroup)
-    while the exact pass, which merges lists, keeps its 2K; the tie-heavy case goes through both."""
+    """Candidate lists of 160 entries and more: the scan keeps lists of K + 64 entries (more waves per workgroup)
+    while the exact pass, which merges lists, keeps its 2K; the tie-heavy cases go through both.  From about
+    k = 500 the finalize step takes its bound from the second to sixteenth entries of the lists instead of their heads."""
     n, d = 120_000, 96
     rows = cases.make_rows(kind, 63, n, d)
     ids = cases.make_ids("hash", 63, n)

@@ -14,6 +14,7 @@
 //                always right, used only for flagged queries (massive ties, adversarial data).
 #include "vdb_internal.h"
 #include "select.h"
+#include <cmath>
 #include <cstring>
 
 namespace vdb {
@@ -592,7 +593,7 @@ int scan_grid(const TableView& t, const SelGeom& g, int n_cu) {
         cap = (long long)n_cu * (bytes < g_tune.short_bytes && g_tune.blocks_per_cu > 2 ? 2 : g_tune.blocks_per_cu);
         // blocks of four to seven waves (candidate lists of 512 to 1024 entries, 48 KiB of lists per block):
         // three such blocks are resident per CU, and that one round is launched
-        if (g.W >= 4 && g.W < 8) cap = (long long)n_cu * 3;
+        if (g.W >= 2 && g.W < 8) cap = (long long)n_cu * 3;
     }
     return (int)(need < cap ? need : cap);
 }
@@ -700,6 +701,8 @@ struct FinParams {
     double           dd_mult, extra_rel, extra_abs, l2_bias;   // see FlatBound
     int              force_exact;
     float*           floor_out;  // lists mode, non-null: only write the K-th best fast key per query and return
+    int              fin_cap;    // lists mode: survivors the kernel's LDS holds (FIN_CAP or FIN_CAP_LONG)
+    int              pth;        // lists mode: which entry of every list the first bound is taken from (fin_pth; 0: the heads, per thread)
 };
 
 __device__ __forceinline__ int pow2_ceil_dev(int v) { int p = 1; while (p < v) p <<= 1; return p; }
@@ -788,7 +791,8 @@ __device__ __forceinline__ bool select_kth(F get, long long count, int K, int* h
     return false;
 }
 
-constexpr int FIN_CAP = 2048;     // survivors of the pre-filter kept in LDS
+constexpr int FIN_CAP = 2048;     // survivors of the pre-filter kept in LDS (FIN_CAP_LONG for lists of more than 512 entries)
+constexpr int FIN_CAP_LONG = 4096;
 constexpr int FIN_RANK_MAX = 256;  // up to this many values are ranked directly (quadratic) instead of radix-selected
 
 // Position of value i among V[0..n) in descending order (ties by index).  Broadcast LDS reads.
@@ -820,8 +824,8 @@ finalize_kernel(FinParams p) {
     float*     SS   = (float*)(ST + K);                 // K selected fast keys
     long long* RT   = (long long*)(SS + K);             // KR re-scored ids
     float*     RS   = (float*)(RT + KR);                // KR re-scored keys
-    float*     VS   = RS + KR;                          // FIN_CAP survivor keys
-    int*       VI   = (int*)(VS + FIN_CAP);             // FIN_CAP survivor positions
+    float*     VS   = RS + KR;                          // fin_cap survivor keys
+    int*       VI   = (int*)(VS + p.fin_cap);           // fin_cap survivor positions
 
     int qi = blockIdx.x;
     if (p.only) { if (qi >= p.only[0]) return; qi = p.only[1 + qi]; }     // block-uniform
@@ -837,7 +841,7 @@ finalize_kernel(FinParams p) {
     bool take_all;
     // diagnostic build only (-DVDB_FIN_STAMPS): stage boundaries of query 0 in 10 ns ticks
 #ifdef VDB_FIN_STAMPS
-#define STAMP(n) do { if (tid == 0 && qi == 0) p.counters[8 + (n)] = (long long)wall_clock64(); } while (0)
+#define STAMP(n) do { if (tid == 0 && qi == 0 && p.counters != nullptr) p.counters[8 + (n)] = (long long)wall_clock64(); } while (0)
 #else
 #define STAMP(n) do { } while (0)
 #endif
@@ -858,11 +862,30 @@ finalize_kernel(FinParams p) {
             head[u] = (u < lpt && b < p.G) ? gh[b] : neg_inf();
             tmax = fmaxf(tmax, head[u]);
         }
-        if ((p.G + lpt - 1) / lpt > K) {
-            // every thread's best head is a distinct candidate: the K-th largest of those (lower
-            // edge of its 16-bit radix bin) is a lower bound of the K-th best key overall
+        // Every thread's best head is a distinct candidate: the K-th largest of those (lower edge of its
+        // 16-bit radix bin) is a lower bound of the K-th best key overall.  When K comes near the number
+        // of threads that hold lists that bound lets everything through; then (p.pth >= 1, chosen by
+        // fin_pth) every list takes part with its pth entry (the lists are sorted, best first):
+        // ceil(K / pth) lists whose pth entry reaches a value hold pth entries each that reach it, K or
+        // more in all.
+        const int T = (p.G + lpt - 1) / lpt;
+        if (p.pth >= 1) {
+            float pv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const long long b = (long long)tid * lpt + u;
+                pv[u] = neg_inf();
+                if (u < lpt && b < p.G) pv[u] = p.pth == 1 ? head[u] : gs[b * K + (p.pth - 1)];
+            }
+            const int Kp = (K + p.pth - 1) / p.pth;
             int nd;
-            const bool all = select_kth([&](long long, int) { return tmax; }, (long long)((p.G + lpt - 1) / lpt), K, hist, ctl, lb, nd, 2);
+            // value (tid, u) is enumerated as index u * nth + tid: u < lpt for every index below nth * lpt
+            const bool all = select_kth([&](long long, int u) { return pv[u]; }, (long long)nth * lpt, Kp, hist, ctl, lb, nd, 2);
+            if (all) lb = 0;
+            __syncthreads();
+        } else if (T > K) {
+            int nd;
+            const bool all = select_kth([&](long long, int) { return tmax; }, (long long)T, K, hist, ctl, lb, nd, 2);
             if (all) lb = 0;
             __syncthreads();
         }
@@ -880,7 +903,7 @@ finalize_kernel(FinParams p) {
                         const float x = v[e];
                         if (more && x > neg_inf() && fkey(x) >= lb) {
                             const int pos = atomicAdd(&ctl[5], 1);
-                            if (pos < FIN_CAP) { VS[pos] = x; VI[pos] = (int)(b * K + i + e); }
+                            if (pos < p.fin_cap) { VS[pos] = x; VI[pos] = (int)(b * K + i + e); }
                         } else {
                             more = false;
                         }
@@ -910,7 +933,7 @@ finalize_kernel(FinParams p) {
                     if (lane == 0) base = atomicAdd(&ctl[5], __popcll(m));
                     base = __shfl(base, 0);
                     const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-                    if (pass && pos < FIN_CAP) { VS[pos] = v[u]; VI[pos] = (int)(i0 + (long long)u * nth + tid); }
+                    if (pass && pos < p.fin_cap) { VS[pos] = v[u]; VI[pos] = (int)(i0 + (long long)u * nth + tid); }
                 }
             }
         }
@@ -930,7 +953,7 @@ finalize_kernel(FinParams p) {
         __syncthreads();
         thr = (uint32_t)ctl[7];
         if (tid == 0) ctl[4] = S;
-    } else if (S <= FIN_CAP) {
+    } else if (S <= p.fin_cap) {
         // (C) exact K best among the survivors
         take_all = select_kth([&](long long j, int) { return VS[j]; }, (long long)S, K, hist, ctl, thr, need);
         for (int j = tid; j < S; j += nth) {
@@ -1196,6 +1219,34 @@ RowBound l2_row_bound(const FlatBound& fb, int d, const QInfo* qinfo, int nq) {
     return rb;
 }
 
+// Which entry of the lists the finalize kernel's first bound is taken from.  0: the K-th largest of the per-thread
+// best heads, which is cheapest and tight while the threads holding lists outnumber K two to one.  Otherwise every
+// list takes part with its p-th entry, p in {1, 2, 4, 8, 16} chosen for the fewest expected survivors: with rows
+// dealt to the G lists at random, a list holds Poisson(lambda) rows above a value that N = lambda * G rows reach,
+// and the bound is the value that ceil(K / p) of the G lists reach with p rows.
+static int fin_pth(int G, int K) {
+    const int nth = 1024;
+    if (G > 8 * nth) return 0;                           // the kernel ranks the heads from memory
+    const int lpt = (G + nth - 1) / nth;
+    if ((G + lpt - 1) / lpt >= 2 * K) return 0;
+    int best = 0;
+    double best_n = 1e300;
+    for (int p = 1; p <= 16; p <<= 1) {
+        const double f = (double)((K + p - 1) / p) / (double)G;      // share of the lists that must reach the bound
+        if (f >= 0.95) continue;
+        double lo = 0.0, hi = 64.0;
+        for (int it = 0; it < 60; ++it) {
+            const double lam = 0.5 * (lo + hi);
+            double term = std::exp(-lam), below = 0.0;               // P(X < p)
+            for (int i = 0; i < p; ++i) { below += term; term *= lam / (i + 1); }
+            if (1.0 - below < f) lo = lam; else hi = lam;
+        }
+        const double n = hi * G;
+        if (n < best_n) { best_n = n; best = p; }
+    }
+    return best;
+}
+
 hipError_t launch_finalize(const TableView& t, const float* qprep, const QInfo* qinfo, int64_t nq,
                            int dpad, const SelGeom& g, int G, int k,
                            const float* cand_s, const long long* cand_t, const float* cand_h,
@@ -1210,8 +1261,10 @@ hipError_t launch_finalize(const TableView& t, const float* qprep, const QInfo* 
     p.need_exact = need_exact; p.counters = counters;
     p.flat_cnt = nullptr; p.flat_cap = 0; p.flat_tau = nullptr; p.flat_lost = nullptr; p.flat_bad = nullptr;
     p.dd_mult = fb.dd_mult; p.extra_rel = fb.extra_rel; p.extra_abs = fb.extra_abs; p.l2_bias = 0.0; p.force_exact = fb.force_exact; p.floor_out = nullptr;
+    p.pth = fin_pth(G, g.K);
     int kr = 1; while (kr < g.K) kr <<= 1;
-    const size_t lds = 1088 + (size_t)g.K * 12 + (size_t)kr * 12 + (size_t)FIN_CAP * 8;
+    p.fin_cap = g.K > 512 ? FIN_CAP_LONG : FIN_CAP;
+    const size_t lds = 1088 + (size_t)g.K * 12 + (size_t)kr * 12 + (size_t)p.fin_cap * 8;
     hipError_t e = allow_lds(finalize_kernel, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)nq), dim3(1024), lds, st, p);
@@ -1226,8 +1279,10 @@ hipError_t launch_lists_floor(const SelGeom& g, int G, int64_t nq, const float* 
     p.K = g.K; p.C = g.C; p.G = G; p.k = 1;
     p.cand_s = cand_s; p.cand_t = cand_t; p.cand_h = cand_h;
     p.floor_out = floor_out;
+    p.pth = fin_pth(G, g.K);
     int kr = 1; while (kr < g.K) kr <<= 1;
-    const size_t lds = 1088 + (size_t)g.K * 12 + (size_t)kr * 12 + (size_t)FIN_CAP * 8;
+    p.fin_cap = g.K > 512 ? FIN_CAP_LONG : FIN_CAP;
+    const size_t lds = 1088 + (size_t)g.K * 12 + (size_t)kr * 12 + (size_t)p.fin_cap * 8;
     hipError_t e = allow_lds(finalize_kernel, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)nq), dim3(1024), lds, st, p);
@@ -1247,7 +1302,7 @@ hipError_t launch_finalize_flat(const TableView& t, const float* qprep, const QI
     p.cand_s = cand_s; p.cand_t = cand_t; p.cand_h = nullptr;
     p.out_ids = out_ids; p.out_scores = out_scores; p.out_counts = out_counts;
     p.need_exact = need_exact; p.counters = counters;
-    p.flat_cnt = cnt; p.flat_cap = cap; p.flat_tau = tau; p.flat_lost = lost; p.flat_bad = bad;
+    p.flat_cnt = cnt; p.flat_cap = cap; p.flat_tau = tau; p.flat_lost = lost; p.flat_bad = bad; p.pth = 0; p.fin_cap = 0;
     p.dd_mult = fb.dd_mult; p.extra_rel = fb.extra_rel; p.extra_abs = fb.extra_abs; p.l2_bias = fb.l2_bias; p.force_exact = fb.force_exact; p.floor_out = nullptr;
     const size_t lds = 1088 + (size_t)BAND_CAP * 20;
     hipError_t e = allow_lds(finalize_band_kernel, lds);

@@ -242,7 +242,7 @@ static SelGeom scan_geom(const SelGeom& g, int max_waves) {
     // longer lists keep the common geometry: more lists per query would cost the finalize step more than the
     // scan gains (its bound from the list heads lets everything through once K comes near the number of
     // heads it ranks: 1 M x 768 at k = 800 fell from 680 to 380 QPS)
-    if (w < 4 || g.K > 640) return g;
+    if (w < 2) return g;
     if (max_waves > 0 && max_waves < w) w = max_waves;
     s.W = w;
     return s;
