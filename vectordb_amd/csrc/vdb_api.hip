@@ -230,7 +230,8 @@ SelGeom sel_geom(int k) {
 
 // Lists of the scan itself: a scanning wave never merges two lists (it hands its own over), so its list
 // needs room for K entries and one wave step of appends, not for two lists as the merges of the exact
-// pass do.  Same K; for K of 160 to 640 a smaller list and more waves per workgroup (k = 256: 8 waves instead of 4).
+// pass do.  Same K; from K = 160 on a smaller list and more waves per workgroup (k = 256: 8 waves instead of 4,
+// k = 1000: 2 instead of 1).  The finalize step copes with the larger number of lists per query (fin_pth).
 static SelGeom scan_geom(const SelGeom& g, int max_waves) {
     SelGeom s = g;
     s.C = 64;
@@ -239,10 +240,7 @@ static SelGeom scan_geom(const SelGeom& g, int max_waves) {
     int w = 4096 / s.C;
     if (w > 16) w = 16;
     if (w < 1) w = 1;
-    // longer lists keep the common geometry: more lists per query would cost the finalize step more than the
-    // scan gains (its bound from the list heads lets everything through once K comes near the number of
-    // heads it ranks: 1 M x 768 at k = 800 fell from 680 to 380 QPS)
-    if (w < 2) return g;
+    if (w < 2) return g;           // one wave per workgroup either way: nothing to gain
     if (max_waves > 0 && max_waves < w) w = max_waves;
     s.W = w;
     return s;
