@@ -87,8 +87,9 @@ int vdb_shutdown(void);
  * type, two products per term; default 0: rounded once),
  * "gemm32s_threads" (workgroup shape of the 256-query tile: 512 = 8 waves over 256 rows (default),
  * 256 = 4 waves over 128 rows, two workgroups per CU).
- * "gemm_pp" (1 = batches of more than 128 queries run on the 256 x 256-tile kernel that loads its
+ * "gemm_pp" (1 = batches of more than 128 queries run on the ping-pong kernel that loads its
  * operands straight into LDS (default); 0 = the converting kernel for every batch size),
+ * "gemm_pp_tile" (rows per tile of that kernel: 384 = 384 x 256 tiles (default), 256 = 256 x 256 tiles),
  * "gemm_pp_parts" (1 = the last pass of that kernel tightens its threshold after an eighth of the
  * rows (default)).
  * Store: "bf16_mirror" (1 = fp32 tables keep a bf16 copy of their rows, half of the table again in

@@ -23,6 +23,9 @@ template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N < 63 ? N : 63) : "memory"); }
 
 // METHOD 0: global_load_lds_dwordx4.  METHOD 1: global_load_dwordx4 + ds_write_b128.
+// METHOD 2: the streamed half by global_load_lds_dwordx4, the hot half by global_load_dwordx4 into
+// registers that never go to LDS (what fragment-ordered query loads straight to VGPRs would do).
+// METHOD 3: as 2 with every hot piece loaded twice (two waves of a workgroup need the same query fragment).
 // Half of every stage comes from `stream` (each byte read once: HBM), half from `hot` (a buffer of
 // hot_bytes that every workgroup re-reads: L2), as the row and query operands of the GEMM do.
 template <int METHOD, int WAVES, int DEPTH, int SEG = 0>
@@ -38,6 +41,7 @@ fill_kernel(const char* __restrict__ stream, const char* __restrict__ hot, size_
     const char* sbase = stream + (size_t)(blockIdx.x % (gridDim.x / share)) * stages * (stream_only ? STAGE : STAGE / 2);
     unsigned acc = 0;
     u32x4 regs[DEPTH][PER];
+    u32x4 regs2[METHOD == 3 ? DEPTH : 1][PER];
     auto issue = [&](long s, auto bufc) __attribute__((always_inline)) {
         constexpr int buf = decltype(bufc)::value;
 #pragma unroll
@@ -67,6 +71,12 @@ fill_kernel(const char* __restrict__ stream, const char* __restrict__ hot, size_
             char* dst = smem + buf * STAGE + piece * 1024;
             if constexpr (METHOD == 0) {
                 __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)src, (LOCAL_AS void*)dst, 16, 0, 0);
+            } else if constexpr (METHOD >= 2) {
+                if (from_stream) __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)src, (LOCAL_AS void*)dst, 16, 0, 0);
+                else {
+                    regs[buf][i] = *(const u32x4*)src;
+                    if constexpr (METHOD == 3) regs2[buf][i] = *(const u32x4*)(hot + (((size_t)(src - hot) + 4096) % hot_bytes));
+                }
             } else {
                 regs[buf][i] = __builtin_nontemporal_load((const u32x4*)src);
             }
@@ -82,6 +92,13 @@ fill_kernel(const char* __restrict__ stream, const char* __restrict__ hot, size_
             issue(nx < stages ? nx : stages - 1, std::integral_constant<int, (buf + DEPTH - 1) % DEPTH>{});
             if constexpr (METHOD == 0) {
                 wait_vm<(DEPTH - 1) * PER>();
+            } else if constexpr (METHOD == 2 || METHOD == 3) {
+                constexpr int LPS = METHOD == 3 ? PER + PER / 2 : PER;      // loads per stage and wave
+                wait_vm<(DEPTH - 1) * LPS>();
+                static_for<PER>([&](auto ic) __attribute__((always_inline)) {
+                    constexpr int i = decltype(ic)::value;
+                    if (i >= PER / 2) { acc ^= regs[buf][i][0] ^ regs[buf][i][3]; if constexpr (METHOD == 3) acc ^= regs2[buf][i][1]; }
+                });
             } else {
                 // the loads of stage s are the oldest PER in flight
                 static_for<PER>([&](auto ic) __attribute__((always_inline)) {
@@ -141,7 +158,11 @@ int main(int argc, char** argv) {
         run<1, 8, 2>("registers 8 waves 2 stages", stream, sb4, hot, hot_bytes, blocks, 0, 4, sink, ghz);
         run<1, 8, 3>("registers 8 waves 3 stages", stream, sb4, hot, hot_bytes, blocks, 0, 4, sink, ghz);
         run<1, 16, 3>("registers 16 waves 3 stages", stream, sb4, hot, hot_bytes, blocks, 0, 4, sink, ghz);
+        run<2, 8, 4>("rows lds-dma, queries to VGPRs", stream, sb4, hot, hot_bytes, blocks, 0, 4, sink, ghz);
+        run<3, 8, 4>("same, query pieces loaded twice", stream, sb4, hot, hot_bytes, blocks, 0, 4, sink, ghz);
     }
+    run<2, 8, 4>("rows lds-dma, queries to VGPRs", stream, stream_bytes, hot, hot_bytes, cus, 0, 1, sink, ghz);
+    run<3, 8, 4>("same, query pieces loaded twice", stream, stream_bytes, hot, hot_bytes, cus, 0, 1, sink, ghz);
     // row-major row operand, one query tile (nothing shared): 64-byte and 128-byte row segments per stage
     run<0, 8, 4, 64>("lds-dma 8w 4st, rows 64 B/stage", stream, stream_bytes, hot, hot_bytes, cus, 0, 1, sink, ghz);
     run<0, 8, 4, 128>("lds-dma 8w 4st, rows 128 B/stage", stream, stream_bytes, hot, hot_bytes, cus, 0, 1, sink, ghz);

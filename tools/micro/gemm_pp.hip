@@ -3,6 +3,7 @@
 //   gemm_pp time [rows] [nq] [dim] [reps] [l2]
 #include "../../vectordb_amd/csrc/gemm_pp.h"
 #include "gemm_pp4.h"
+#include "../../vectordb_amd/csrc/gemm_pp384.h"
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -45,7 +46,8 @@ __global__ void norms_kernel(const unsigned short* X, long long ldx, long long n
     n2[r] = a;
 }
 
-static int g_shape = 32, g_tiled = 1, g_kernel = 8;       // g_kernel 4: the four-wave form (gemm_pp4.h)
+static int g_shape = 32, g_tiled = 1, g_kernel = 8;       // g_kernel 4: the four-wave form (gemm_pp4.h); 3: 384 x 256 tiles (gemm_pp384.h)
+static long long tile_rows() { return g_kernel == 3 ? 384 : 256; }
 template <bool L2M, bool DENSE, int SHAPE, bool TILED>
 static void launch_v(const GemmPPParams& p, int gx, int qtiles) {
     const int lds = L2M ? PP_LDS_L2 : PP_LDS_IP;
@@ -62,8 +64,27 @@ static void launch_4(const GemmPPParams& p, int gx, int qtiles) {
     hipLaunchKernelGGL((gemm_pp4_kernel<1, L2M, DENSE, TILED>), dim3(gx, qtiles), dim3(256), lds, 0, p);
     CK(hipGetLastError());
 }
+static int g_var = 0;
+template <bool L2M, bool DENSE, bool TILED, int VAR>
+static void launch_384v(const GemmPPParams& p, int gx, int qtiles) {
+    static bool once = false;
+    if (!once) { CK(hipFuncSetAttribute((const void*)gemm_pp384_kernel<1, L2M, DENSE, TILED, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, PW_LDS)); once = true; }
+    hipLaunchKernelGGL((gemm_pp384_kernel<1, L2M, DENSE, TILED, VAR>), dim3(gx, qtiles), dim3(512), PW_LDS, 0, p);
+    CK(hipGetLastError());
+}
+template <bool L2M, bool DENSE>
+static void launch_384(const GemmPPParams& p, int gx, int qtiles) {
+    if (g_tiled) { if (g_var & 2) launch_384v<L2M, DENSE, true, 2>(p, gx, qtiles); else launch_384v<L2M, DENSE, true, 0>(p, gx, qtiles); return; }
+    switch (g_var) {
+        case 1: launch_384v<L2M, DENSE, false, 1>(p, gx, qtiles); break;
+        case 2: launch_384v<L2M, DENSE, false, 2>(p, gx, qtiles); break;
+        case 3: launch_384v<L2M, DENSE, false, 3>(p, gx, qtiles); break;
+        default: launch_384v<L2M, DENSE, false, 0>(p, gx, qtiles); break;
+    }
+}
 template <bool L2M, bool DENSE>
 static void launch_d(const GemmPPParams& p, int gx, int qtiles) {
+    if (g_kernel == 3) { launch_384<L2M, DENSE>(p, gx, qtiles); return; }
     if (g_kernel == 4) { if (g_tiled) launch_4<L2M, DENSE, true>(p, gx, qtiles); else launch_4<L2M, DENSE, false>(p, gx, qtiles); return; }
     if (g_shape == 32) { if (g_tiled) launch_v<L2M, DENSE, 32, true>(p, gx, qtiles); else launch_v<L2M, DENSE, 32, false>(p, gx, qtiles); }
     else { if (g_tiled) launch_v<L2M, DENSE, 16, true>(p, gx, qtiles); else launch_v<L2M, DENSE, 16, false>(p, gx, qtiles); }
@@ -73,19 +94,20 @@ static void launch(const GemmPPParams& p, int gx, int qtiles) {
     if (p.dense) launch_d<L2M, true>(p, gx, qtiles); else launch_d<L2M, false>(p, gx, qtiles);
 }
 // row-major [n][ld] -> tiled image (rows padded to whole tiles with zeros)
-__global__ void tile_kernel(const unsigned short* X, long long ld, long long n, int K, int nks, long long ntile_rows, unsigned short* out) {
+__global__ void tile_kernel(const unsigned short* X, long long ld, long long n, int K, int nks, long long ntile_rows, unsigned short* out, int t384) {
     const long long total = ntile_rows * nks * 32;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const long long row = i / (nks * 32);
         const int col = (int)(i % (nks * 32));
-        out[pp_tiled_index(row, col, nks)] = (row < n && col < K) ? X[row * ld + col] : (unsigned short)0;
+        out[t384 ? pw_tiled_index(row, col, nks) : pp_tiled_index(row, col, nks)] = (row < n && col < K) ? X[row * ld + col] : (unsigned short)0;
     }
 }
-static unsigned short* make_tiled(const unsigned short* X, long long ld, long long n, int K, int nks) {
-    const long long rows = (n + 255) / 256 * 256;
+static unsigned short* make_tiled(const unsigned short* X, long long ld, long long n, int K, int nks, int t384 = 0) {
+    const long long tr = t384 ? 384 : 256;
+    const long long rows = (n + tr - 1) / tr * tr;
     unsigned short* out;
     CK(hipMalloc(&out, (size_t)rows * nks * 32 * 2));
-    tile_kernel<<<4096, 256>>>(X, ld, n, K, nks, rows, out);
+    tile_kernel<<<4096, 256>>>(X, ld, n, K, nks, rows, out, t384);
     CK(hipGetLastError());
     return out;
 }
@@ -108,11 +130,11 @@ static int run_check(long long n, int nq, int K, int l2, long long tile_stride, 
     CK(hipMemcpy(thr, hthr.data(), nq * 4, hipMemcpyHostToDevice));
     GemmPPParams p;
     memset(&p, 0, sizeof p);
-    unsigned short* Xt = make_tiled(X, ldx, n, K, qstride / 32);
+    unsigned short* Xt = make_tiled(X, ldx, n, K, qstride / 32, g_kernel == 3);
     unsigned short* Qt = make_tiled(Q, qstride, nq, K, qstride / 32);
     p.X = g_tiled ? Xt : X; p.n2 = n2; p.Q = Qt; p.thr = thr; p.n = n; p.ldx = ldx; p.nq = nq; p.qstride = qstride; p.nks = qstride / 32;
     p.tile_stride = tile_stride;
-    p.ntiles = ((n + 255) / 256 + tile_stride - 1) / tile_stride;
+    p.ntiles = ((n + tile_rows() - 1) / tile_rows() + tile_stride - 1) / tile_stride;
     p.cand_s = cs; p.cand_t = ct; p.cnt = cnt; p.lost = lost; p.cap = cap; p.dense = dense;
     const int qtiles = (nq + 255) / 256;
     int gx = gx_force > 0 ? gx_force : 8;
@@ -124,7 +146,7 @@ static int run_check(long long n, int nq, int K, int l2, long long tile_stride, 
     CK(hipMemcpy(hr.data(), ref, hr.size() * 4, hipMemcpyDeviceToHost));
     double maxerr = 0; long long bad = 0, visited = 0;
     for (long long r = 0; r < n; ++r) {
-        const bool vis = ((r / 256) % tile_stride) == 0;
+        const bool vis = ((r / tile_rows()) % tile_stride) == 0;
         for (int q = 0; q < nq; ++q) {
             const float a = hd[(size_t)r * nq + q], b = hr[(size_t)r * nq + q];
             if (!vis) continue;
@@ -154,7 +176,7 @@ static int run_check(long long n, int nq, int K, int l2, long long tile_stride, 
     for (int q = 0; q < nq; ++q) {
         nlost += hlost[q] != 0;
         long long want = 0;
-        for (long long r = 0; r < n; ++r) if (((r / 256) % tile_stride) == 0 && hd[(size_t)r * nq + q] > t) ++want;
+        for (long long r = 0; r < n; ++r) if (((r / tile_rows()) % tile_stride) == 0 && hd[(size_t)r * nq + q] > t) ++want;
         // a query whose wave queue overflowed is flagged lost (the library sends it to the exact pass): it may hold fewer
         if (hlost[q] ? hcnt[q] > want : want != hcnt[q]) { if (cbad < 5) printf("  query %d: %d candidates, want %lld\n", q, hcnt[q], want); ++cbad; }
         for (int i = 0; i < hcnt[q] && i < cap; ++i) {
@@ -177,8 +199,9 @@ static void run_time(long long n, int nq, int K, int reps, int l2) {
     CK(hipMalloc(&X, (size_t)n * ldx * 2 + 256)); CK(hipMalloc(&Q, (size_t)nq * qstride * 2));
     CK(hipMalloc(&n2, n * 4)); CK(hipMalloc(&thr, nq * 4));
     CK(hipMalloc(&cs, (size_t)nq * cap * 4)); CK(hipMalloc(&ct, (size_t)nq * cap * 8)); CK(hipMalloc(&cnt, nq * 4)); CK(hipMalloc(&lost, nq * 4));
-    fill_bf16<<<4096, 256>>>(X, n * ldx, 1, 1.0f);
-    fill_bf16<<<256, 256>>>(Q, (long long)nq * qstride, 2, l2 ? -2.0f : 1.0f);
+    const float fscale = getenv("PP_SCALE") ? (float)atof(getenv("PP_SCALE")) : 1.0f;     // 0: all-zero operands (clock check)
+    fill_bf16<<<4096, 256>>>(X, n * ldx, 1, fscale);
+    fill_bf16<<<256, 256>>>(Q, (long long)nq * qstride, 2, (l2 ? -2.0f : 1.0f) * fscale);
     norms_kernel<<<(unsigned)((n + 255) / 256), 256>>>(X, ldx, n, K, n2);
     // threshold about 4.2 sigma of the score distribution: ~ 1e-5 of the rows pass
     const float sigma = sqrtf((float)K) * (getenv("PP_SIGMA") ? (float)atof(getenv("PP_SIGMA")) / 4.2f : 1.0f);
@@ -187,10 +210,10 @@ static void run_time(long long n, int nq, int K, int reps, int l2) {
     CK(hipMemcpy(thr, hthr.data(), nq * 4, hipMemcpyHostToDevice));
     GemmPPParams p;
     memset(&p, 0, sizeof p);
-    unsigned short* Xt = make_tiled(X, ldx, n, K, qstride / 32);
+    unsigned short* Xt = make_tiled(X, ldx, n, K, qstride / 32, g_kernel == 3);
     unsigned short* Qt = make_tiled(Q, qstride, nq, K, qstride / 32);
     p.X = g_tiled ? Xt : X; p.n2 = n2; p.Q = Qt; p.thr = thr; p.n = n; p.ldx = ldx; p.nq = nq; p.qstride = qstride; p.nks = qstride / 32;
-    p.tile_stride = 1; p.ntiles = (n + 255) / 256;
+    p.tile_stride = 1; p.ntiles = (n + tile_rows() - 1) / tile_rows();
     p.cand_s = cs; p.cand_t = ct; p.cnt = cnt; p.lost = lost; p.cap = cap; p.dense = nullptr;
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
     const int qtiles = (nq + 255) / 256;
@@ -225,6 +248,12 @@ static void run_time(long long n, int nq, int K, int reps, int l2) {
         const int nb = gx * qtiles;
         std::vector<double> e(nb);
         for (int i = 0; i < nb; ++i) e[i] = h[i] / 100.0;
+        std::vector<unsigned> hc(4096);
+        CK(hipMemcpyFromSymbol(hc.data(), HIP_SYMBOL(g_pp_clk), 4096 * 4));
+        std::vector<double> ghz(nb);
+        for (int i = 0; i < nb; ++i) ghz[i] = h[i] ? hc[i] / (h[i] * 10.0) : 0;      // cycles per 10 ns tick -> GHz
+        std::sort(ghz.begin(), ghz.end());
+        printf("shader clock over the workgroups' run (GHz): min %.3f median %.3f max %.3f\n", ghz[0], ghz[nb / 2], ghz[nb - 1]);
         std::vector<double> srt(e); std::sort(srt.begin(), srt.end());
         printf("workgroup run times (us): min %.0f p10 %.0f median %.0f p90 %.0f max %.0f\n", srt[0], srt[nb / 10], srt[nb / 2], srt[nb * 9 / 10], srt[nb - 1]);
         for (int x = 0; x < 8; ++x) {
@@ -242,6 +271,8 @@ int main(int argc, char** argv) {
     if (getenv("PP_SHAPE")) g_shape = atoi(getenv("PP_SHAPE")) == 16 ? 16 : 32;
     if (getenv("PP_TILED")) g_tiled = atoi(getenv("PP_TILED"));
     if (getenv("PP_KERNEL")) g_kernel = atoi(getenv("PP_KERNEL"));
+    if (getenv("PP_VAR")) g_var = atoi(getenv("PP_VAR"));
+    if (g_kernel == 3) g_shape = 16;
     if (argc >= 2 && !strcmp(argv[1], "check")) {
         int rc = 0;
         printf("MFMA shape %d tiled %d kernel %d\n", g_shape, g_tiled, g_kernel);

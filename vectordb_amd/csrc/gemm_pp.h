@@ -117,6 +117,7 @@ __device__ __forceinline__ typename PPAcc<SHAPE>::type pp_mfma(const pp_u32x4& a
 #ifdef PP_STAMPS
 // diagnostic build only (tools/micro/gemm_pp.hip): per workgroup, the time from its start to its end in 10 ns ticks
 __device__ unsigned int g_pp_end[4096];
+__device__ unsigned int g_pp_clk[4096];          // shader clock cycles over the same span (clock = cycles / time)
 #endif
 
 template <int DT, bool L2M, bool DENSE, int SHAPE, bool TILED>
@@ -125,6 +126,7 @@ gemm_pp_kernel(GemmPPParams p) {
     extern __shared__ __attribute__((aligned(16))) char pp_smem[];
 #ifdef PP_STAMPS
     const unsigned long long pp_stamp0 = wall_clock64();
+    const unsigned long long pp_clk0 = __builtin_amdgcn_s_memtime();
 #endif
     constexpr int MB = SHAPE;                      // rows (and queries) per MFMA block
     constexpr int NMI = 128 / MB, NNI = 64 / MB;   // blocks per wave tile
@@ -434,7 +436,10 @@ gemm_pp_kernel(GemmPPParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (wm == 0) __builtin_amdgcn_s_barrier();     // matches the extra barrier of waves 4-7
 #ifdef PP_STAMPS
-    if (tid == 0) g_pp_end[(blockIdx.y * gridDim.x + blockIdx.x) & 4095] = (unsigned)(wall_clock64() - pp_stamp0);
+    if (tid == 0) {
+        g_pp_clk[(blockIdx.y * gridDim.x + blockIdx.x) & 4095] = (unsigned)(__builtin_amdgcn_s_memtime() - pp_clk0);
+        g_pp_end[(blockIdx.y * gridDim.x + blockIdx.x) & 4095] = (unsigned)(wall_clock64() - pp_stamp0);
+    }
 #endif
 }
 

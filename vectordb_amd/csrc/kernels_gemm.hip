@@ -21,6 +21,7 @@
 #include "vdb_internal.h"
 #include "select.h"
 #include "gemm_pp.h"
+#include "gemm_pp384.h"
 
 namespace vdb {
 
@@ -1000,6 +1001,19 @@ hipError_t launch_tile_query16(int dt, int l2, const float* qprep, int nq, int d
     return hipGetLastError();
 }
 
+// Rows per tile of the ping-pong pass: 384 (gemm_pp384.h, the default) or 256 (gemm_pp.h).
+static int g_pp_tile_rows = PW_TM;
+void set_pp_tile_rows(int v) { g_pp_tile_rows = v == PP_TM ? PP_TM : PW_TM; }
+int pp_tile_rows() { return g_pp_tile_rows; }
+
+static long long pp_grid_x(const GemmPPParams& p, int n_cu, int qtiles) {
+    long long gx = (long long)n_cu / qtiles;       // one workgroup per CU
+    gx = gx / 8 * 8;                               // the query tiles of one row range share an XCD (and its L2)
+    if (gx < 8) gx = 8;
+    if (gx > p.ntiles) gx = p.ntiles;
+    return gx;
+}
+
 template <int DT, bool L2M>
 static hipError_t launch_gemm_pp_v(const GemmPPParams& p, int n_cu, hipStream_t st) {
     constexpr int lds = L2M ? PP_LDS_L2 : PP_LDS_IP;
@@ -1010,11 +1024,23 @@ static hipError_t launch_gemm_pp_v(const GemmPPParams& p, int n_cu, hipStream_t 
         allowed = true;
     }
     const int qtiles = (p.nq + PP_TN - 1) / PP_TN;
-    long long gx = (long long)n_cu / qtiles;       // one workgroup per CU
-    gx = gx / 8 * 8;                               // the query tiles of one row range share an XCD (and its L2)
-    if (gx < 8) gx = 8;
-    if (gx > p.ntiles) gx = p.ntiles;
+    const long long gx = pp_grid_x(p, n_cu, qtiles);
     hipLaunchKernelGGL((gemm_pp_kernel<DT, L2M, false, 16, false>), dim3((unsigned)gx, (unsigned)qtiles), dim3(512), lds, st, p);
+    return hipGetLastError();
+}
+
+// 384-row tiles, row-major rows, query loads ahead of the row loads of a stage
+template <int DT, bool L2M>
+static hipError_t launch_gemm_pp384_v(const GemmPPParams& p, int n_cu, hipStream_t st) {
+    static bool allowed = false;
+    if (!allowed) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_pp384_kernel<DT, L2M, false, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, PW_LDS);
+        if (e != hipSuccess) return e;
+        allowed = true;
+    }
+    const int qtiles = (p.nq + PW_TN - 1) / PW_TN;
+    const long long gx = pp_grid_x(p, n_cu, qtiles);
+    hipLaunchKernelGGL((gemm_pp384_kernel<DT, L2M, false, false, 2>), dim3((unsigned)gx, (unsigned)qtiles), dim3(512), PW_LDS, st, p);
     return hipGetLastError();
 }
 
@@ -1022,19 +1048,26 @@ hipError_t launch_gemm_pp(const TableView& t, const unsigned short* qimage, int 
                           long long tile_stride, long long tile0, long long tile_count,
                           float* cand_s, long long* cand_t, int* cnt, int* lost, int cap,
                           int n_cu, hipStream_t st) {
+    const int TR = g_pp_tile_rows;
     GemmPPParams p;
     p.X = t.rows16; p.n2 = t.n2; p.rb = t.rb; p.Q = qimage; p.thr = thr; p.n = t.n; p.ldx = t.ld16; p.nq = nq;
     p.qstride = 0; p.nks = pp_nks(dpad);
     p.tile_stride = tile_stride < 1 ? 1 : tile_stride;
-    p.ntiles = ((t.n + PP_TM - 1) / PP_TM + p.tile_stride - 1) / p.tile_stride;
+    p.ntiles = ((t.n + TR - 1) / TR + p.tile_stride - 1) / p.tile_stride;
     // a range of the visited tiles: [tile0, tile0 + tile_count) of them (tile_count < 0: to the end)
     p.tile0 = tile0 * p.tile_stride;
     p.ntiles -= tile0;
     if (tile_count >= 0 && tile_count < p.ntiles) p.ntiles = tile_count;
     p.cand_s = cand_s; p.cand_t = cand_t; p.cnt = cnt; p.lost = lost; p.cap = cap; p.dense = nullptr;
     if (p.ntiles <= 0) return hipSuccess;
+    // the kernels address a row with 32-bit byte offsets inside a tile and queries with 32-bit indices
+    if (t.ld16 <= 0 || t.ld16 > (1 << 20) || nq <= 0) return hipErrorInvalidValue;
     const bool l2 = t.metric == VDB_METRIC_L2;
     const int dt = t.dt == VDB_F16 ? VDB_F16 : VDB_BF16;       // fp32 tables multiply their bf16 mirror
+    if (TR == PW_TM) {
+        if (dt == VDB_BF16) return l2 ? launch_gemm_pp384_v<VDB_BF16, true>(p, n_cu, st) : launch_gemm_pp384_v<VDB_BF16, false>(p, n_cu, st);
+        return l2 ? launch_gemm_pp384_v<VDB_F16, true>(p, n_cu, st) : launch_gemm_pp384_v<VDB_F16, false>(p, n_cu, st);
+    }
     if (dt == VDB_BF16) return l2 ? launch_gemm_pp_v<VDB_BF16, true>(p, n_cu, st) : launch_gemm_pp_v<VDB_BF16, false>(p, n_cu, st);
     return l2 ? launch_gemm_pp_v<VDB_F16, true>(p, n_cu, st) : launch_gemm_pp_v<VDB_F16, false>(p, n_cu, st);
 }

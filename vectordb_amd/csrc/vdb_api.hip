@@ -535,8 +535,8 @@ static int search_gemm_path(const TableView& tv_in, const SelGeom& g, int dpad, 
             // the other seven eighths (candidates per query at 10 M rows: 2000 -> 500).  Candidates of both
             // parts stay in the array; the finalize step is told the tighter threshold, which is valid
             // for every row that is not a candidate.
-            const long long t256 = (tv.n + 255) / 256;
-            const long long part = G.tune_pp_parts ? t256 / 8 : 0;
+            const long long tpp = (tv.n + pp_tile_rows() - 1) / pp_tile_rows();
+            const long long part = G.tune_pp_parts ? tpp / 8 : 0;
             if (part >= 4LL * G.n_cu) {
                 VDB_HIP(launch_gemm_pp(tv, qimg, nqi, dpad, tau, 1, 0, part, cs, ct, cnt, lost, GEMM_CAP, G.n_cu, st));
                 VDB_HIP(launch_kth_threshold(cs, GEMM_CAP, cnt, 0, GEMM_CAP, K, tau, spare, nqi, st));
@@ -924,6 +924,7 @@ int vdb_set_option(const char* key, double value) {
     else if (k == "gemm_split_bf16") G.tune_split_bf16 = value != 0;
     else if (k == "gemm32s_threads") set_gemm32s_threads((int)value);
     else if (k == "gemm_pp") G.tune_pp = value != 0;
+    else if (k == "gemm_pp_tile") set_pp_tile_rows((int)value);
     else if (k == "force_exact") G.force_exact = value != 0;
     else if (k == "gemm_pp_parts") G.tune_pp_parts = value != 0;
     else if (k == "scan_mirror") G.scan_mirror = value != 0;
