@@ -69,10 +69,23 @@ def cpu_baseline(rows_total: int, dim: int, k: int, metric_name: str, budget_s: 
         if el >= budget_s or done >= 2000:
             break
     qps_sample = done / el
+    cpu_model = ""
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                if ln.lower().startswith("model name"):
+                    cpu_model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
     return {
         "value": qps_sample * sample_rows / rows_total,
         "unit": "QPS",
         "cores": int(threads),
+        "os_cpu_count": os.cpu_count(),
+        "cpu_model": cpu_model,
+        "openblas_num_threads": os.environ.get("OPENBLAS_NUM_THREADS"),
+        "omp_num_threads": os.environ.get("OMP_NUM_THREADS"),
         "kind": "port",
         "sample": "%d queries in %.1f s on %d x %d fp32 rows (numpy %s sgemv + argpartition + fp64 re-score of "
                   "k+54 candidates), QPS scaled by %d/%d rows" % (done, el, sample_rows, dim, np.__version__,
@@ -127,6 +140,10 @@ def main() -> None:
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="0 disables the CPU baseline")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (nccl = RCCL; gloo rehearses the path on fewer GPUs)")
+    ap.add_argument("--trace-steps", type=int, default=0,
+                    help="after the timed region, this many extra steps are broken down per phase (local search, "
+                         "collective, merge): host microseconds to enqueue each, and microseconds until each has "
+                         "completed on the device")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the other BASELINE configurations measured after the headline on one GPU")
     args = ap.parse_args()
@@ -234,6 +251,25 @@ def rank_main(args, world: int) -> None:
         last_ids = out.ids.cpu().numpy().copy()
         last_scores = out.scores.cpu().numpy().copy()
 
+        # per-phase breakdown of a step, outside the timed region: what the host spends enqueueing each
+        # phase while steps are pipelined, and how long each phase takes on the device when nothing overlaps
+        trace = None
+        if args.trace_steps > 0:
+            trace = {}
+            for label, sync in (("host_enqueue_us", False), ("device_complete_us", True)):
+                for s in searchers:
+                    s.trace, s.trace_sync = [], sync
+                for j in range(args.trace_steps):
+                    step(warmup + (j % max(1, steps)))
+                    if sync:
+                        torch.cuda.synchronize()
+                fence()
+                rows_ = np.array([t for s in searchers for t in s.trace], dtype=np.float64).reshape(-1, 3)
+                trace[label] = {"local_search": float(np.median(rows_[:, 0])), "collective": float(np.median(rows_[:, 1])),
+                                "merge": float(np.median(rows_[:, 2])), "steps": int(rows_.shape[0]), "stat": "median"}
+                for s in searchers:
+                    s.trace, s.trace_sync = None, False
+
         # request latency through the host entry point (vdb_search: H2D of the query, the same kernels,
         # D2H of ids and scores), one blocking call at a time -- outside the timed region, on queries of
         # its own
@@ -298,6 +334,8 @@ def rank_main(args, world: int) -> None:
             "host_latency_ms": host_lat,
             "sample_result": {"ids": [int(x) for x in last_ids[0][:3]], "scores": [float(x) for x in last_scores[0][:3]]},
         }
+        if trace is not None:
+            entry["trace"] = trace
         if mirror and nq == 1:
             entry["dtype"] = "f32 rows; scan over their bf16 mirror, f32 accumulate; fp64 re-score of the candidates from the f32 rows"
             entry["roofline"]["kernel"] = "scan_kernel (bf16 mirror)"
@@ -453,6 +491,8 @@ def rank_main(args, world: int) -> None:
             "host_latency_ms": main_e["host_latency_ms"],
             "sample_result": main_e["sample_result"],
         }
+        if "trace" in main_e:
+            line["trace"] = main_e["trace"]
         if secondary:
             line["secondary"] = secondary
         if world == 1 and args.cpu_seconds > 0 and args.nq == 1:

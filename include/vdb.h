@@ -18,8 +18,12 @@
  *     and merge `_dev` calls enqueue their work on that stream and return
  *     without synchronising, vdb_insert_dev waits for its stream before it
  *     returns (the new rows are then visible to searches on any stream);
- *   - thread safety: any number of concurrent searches; inserts on a table are
- *     serialised and exclude searches on that table while rows are added
+ *   - thread safety: any number of concurrent searches and inserts.  Inserts on a
+ *     table are serialised among themselves and do not stall searches: new rows are
+ *     written behind the published row count and become visible with one atomic
+ *     store once the whole call has landed, so a search sees all rows of an insert
+ *     or none; tables grow in place (reserved virtual ranges), nothing a search
+ *     reads ever moves.  Only vdb_drop_table waits for the work in flight
  *     (the reference serves each HTTP request on its own thread against one
  *     process-global engine handle with no locking: app.py:11-12,186-190);
  *   - there is no CPU fallback: without a usable GPU vdb_init fails.
@@ -148,11 +152,20 @@ int vdb_fetch_rows(const char* name, int64_t first, int64_t n, float* out_rows, 
  * (/root/reference/server_config.yaml:12, :22), which the Milvus server the reference talks to
  * uses to keep tables across restarts and to bring them into memory at start-up.
  * vdb_save_table writes the stored (quantised, for COSINE normalised) rows, ids and row norms of
- * one table to `path` (written under a temporary name, then renamed).  vdb_load_table creates
- * table `name` from such a file: VDB_EEXISTS if the name is taken, VDB_ENOTFOUND if the file
- * cannot be opened, VDB_EINVAL if it is not a complete snapshot.  A loaded table answers every
- * search with the same ids and scores as the table that was saved. */
+ * one table to `path`.  The first save of a table to a path writes the whole table under a temporary
+ * name and renames it.  A later save of the same table (same identity: a table that was created, or
+ * loaded from that file, and has only grown since) to the same path is incremental: it appends one
+ * segment with the rows that arrived since the last save and rewrites the header last, so the file
+ * reads as the older snapshot until the new rows are complete; the cost is that of the new rows.
+ * The reference's engine persists every insert under primary_path, and its /insert relies on that
+ * (a hash already in the relational table is never sent to the engine again, app.py:293-295);
+ * incremental saves are what makes frequent snapshots affordable here.
+ * vdb_save_table_rows is the same call and also reports how many rows it wrote.
+ * vdb_load_table creates table `name` from such a file: VDB_EEXISTS if the name is taken,
+ * VDB_ENOTFOUND if the file cannot be opened, VDB_EINVAL if it is not a complete snapshot.  A loaded
+ * table answers every search with the same ids and scores as the table that was saved. */
 int vdb_save_table(const char* name, const char* path);
+int vdb_save_table_rows(const char* name, const char* path, int64_t* out_rows_written);
 int vdb_load_table(const char* name, const char* path);
 
 /* ---- search: replaces search_vectors(table_name, query_records, top_k, nprobe) (app.py:384-391)
@@ -172,13 +185,15 @@ int vdb_search_dev(const char* name, int64_t nq, const float* queries_dev, int k
                    void* stream);
 
 /* No counterpart in the reference.  The same search as vdb_search_dev for callers that cannot
- * allocate device memory (code under HIP graph capture, tight serving loops, harnesses that forbid
- * it): the call allocates, creates and frees nothing.  Its intermediate buffers live in a 24 MiB
+ * allocate device memory (tight serving loops, harnesses that forbid it): the call allocates,
+ * creates and frees nothing (no device memory, stream or event).  Its intermediate buffers live in a 24 MiB
  * array inside the library's code object (each GPU the library runs on holds its copy until the
  * process ends); a search that needs more (many queries per call, a large k: about 3.1 MiB per query
  * at k = 10 on a large table, 12.6 MiB at k = 100) is refused with VDB_EINVAL, as are more than 256
  * queries per call.  Every query runs as a scan (no batched path); results are those of
- * vdb_search_dev bit for bit.  All calls on one GPU share the array: calls that overlap in time race. */
+ * vdb_search_dev bit for bit.  All calls on one GPU share the array: a call made while another
+ * thread is inside the entry point is refused with VDB_ESTATE; calls on one stream are kept apart by
+ * stream order; calls on different streams must be ordered by the caller. */
 int vdb_search_dev_noalloc(const char* name, int64_t nq, const float* queries_dev, int k,
                            int64_t* out_ids_dev, float* out_scores_dev, int32_t* out_counts_dev,
                            void* stream);

@@ -50,6 +50,8 @@ def create_app(client: Milvus = None, store: MetaStore = None, compat_lookup: bo
     app = Flask(__name__)
     state = {"client": client, "store": store or MetaStore(os.environ.get("VDB_META_PATH", ":memory:"))}
     lock = threading.Lock()
+    # requests that carry the same vector hash take turns from the bookkeeping to the engine insert
+    hash_locks = [threading.Lock() for _ in range(64)]
     compat_bug = (os.environ.get("VDB_COMPAT_LOOKUP_BUG", "1") != "0") if compat_lookup is None else bool(compat_lookup)
 
     def engine() -> Milvus:
@@ -107,13 +109,40 @@ def create_app(client: Milvus = None, store: MetaStore = None, compat_lookup: bo
 
     @app.route("/checkintegrity")
     def check_integrity():
+        # Beyond the reference's check (does every database have an engine table, app.py:194-225): do both
+        # sides hold the same vectors?  /insert never sends a known hash to the engine again
+        # (app.py:293-295), so a hash that is known here and missing there (rows that arrived after the last
+        # snapshot of a restarted engine) would stay missing without anybody noticing.
         all_good = True
+        details = []
         print("Table name\tExists in postgres\tExists in Milvus")
         for name, _, _, _ in store_().list_dbs():
             status, in_engine = engine().has_table(name)
             print(name + "\t\tTrue\t\t\t\t" + str(in_engine))
             all_good = all_good and in_engine
-        return "All ok" if all_good else "DB integrety bad. Check server output for details"
+            if not in_engine:
+                details.append("%s: no engine table" % name)
+                continue
+            client = engine()
+            if not hasattr(client, "get_table_row_count"):
+                continue
+            st, stored = client.get_table_row_count(name)
+            known = store_().hashes(name)
+            if st.OK() and stored == len(known):
+                continue
+            all_good = False
+            line = "%s: %d vector hashes known, %d vectors stored" % (name, len(known), stored)
+            if hasattr(client, "table_ids"):
+                st, ids = client.table_ids(name)
+                if st.OK():
+                    have = set(int(i) for i in ids)
+                    missing = sorted(h for h in known if h not in have)
+                    line += "; known but not stored: %d %s" % (len(missing), json.dumps(missing[:50]))
+            print(line)
+            details.append(line)
+        if all_good:
+            return "All ok"
+        return "DB integrety bad. Check server output for details" + "".join("\n" + d for d in details)
 
     @app.route("/createdb")
     def create_new_db():
@@ -161,17 +190,25 @@ def create_app(client: Milvus = None, store: MetaStore = None, compat_lookup: bo
         body = request.json
         asset_id, vector = body["name"], body["vector"]
         vector_hash = hash_vector(vector)
-        try:
-            is_new = store_().add_mapping(name, vector_hash, asset_id)
-        except (MetaStoreError, Exception) as exc:      # unknown database etc.
-            return "Error: " + str(exc), 400
-        if is_new:
-            result = engine().insert(name, records=[vector], ids=[vector_hash])
-            status = result[0] if isinstance(result, tuple) else result
-            if not status.OK():
-                # the vector is not stored: forget the mapping, or every retry would find the hash known
-                store_().remove_mapping(name, vector_hash, asset_id)
-                return "Error: " + status.message, 500
+        # One request at a time per hash, from the bookkeeping to the engine: a second request with the same
+        # vector must not find the hash "known" while the first one's engine insert can still be refused.
+        with hash_locks[vector_hash % len(hash_locks)]:
+            try:
+                is_new = store_().add_mapping(name, vector_hash, asset_id)
+            except (MetaStoreError, Exception) as exc:      # unknown database etc.
+                return "Error: " + str(exc), 400
+            if is_new:
+                stored, message = False, "engine insert failed"
+                try:
+                    result = engine().insert(name, records=[vector], ids=[vector_hash])
+                    status = result[0] if isinstance(result, tuple) else result
+                    stored, message = status.OK(), status.message
+                finally:
+                    if not stored:
+                        # the vector is not stored: forget the hash, or every retry would find it known
+                        store_().remove_hash(name, vector_hash)
+                if not stored:
+                    return "Error: " + message, 500
         return "hej"                                     # app.py:349
 
     @app.route("/lookupexact", methods=["PUT"])

@@ -83,6 +83,18 @@ class MetaStore:
         with self._lock, self._db:
             self._db.execute("DELETE FROM %s WHERE vector_hash = ? AND asset_id = ?" % name, (vector_hash, str(asset_id)))
 
+    def remove_hash(self, name: str, vector_hash: int) -> None:
+        """Forget every asset of a hash whose vector the engine refused."""
+        check_name(name)
+        with self._lock, self._db:
+            self._db.execute("DELETE FROM %s WHERE vector_hash = ?" % name, (vector_hash,))
+
+    def hashes(self, name: str) -> List[int]:
+        """Distinct vector hashes of a database: the ids its engine table should hold."""
+        check_name(name)
+        with self._lock:
+            return [r[0] for r in self._db.execute("SELECT DISTINCT vector_hash FROM %s" % name)]
+
     def assets(self, name: str, vector_hash: int) -> List[str]:
         check_name(name)
         with self._lock:

@@ -221,3 +221,48 @@ def test_concurrent_lookups_are_merged_and_stay_exact(engine):
     assert m.delete_table(name).OK()
     status, results = m.search_vectors(table_name=name, query_records=[qlists[0]], top_k=k, nprobe=10)
     assert not status.OK() and results == []
+
+
+def test_integrity_after_restart_reports_the_unsaved_vectors(engine, tmp_path):
+    """engine_config.snapshot_every_rows writes incremental snapshots while vectors arrive; after a restart
+    (HBM copy gone, relational side kept) /checkintegrity names exactly the vectors that arrived after the
+    last snapshot: /insert would never send their hashes to the engine again (/root/reference/app.py:293-295)."""
+    import struct
+    from server.app import create_app
+    from server.metastore import MetaStore
+    from vectordb_amd import milvus as M
+    from vectordb_amd.config import EngineConfig, parse_config
+    assert parse_config({"engine_config": {"snapshot_every_rows": 25}}).snapshot_every_rows == 25
+    cfg = EngineConfig(primary_path=str(tmp_path / "data"), snapshot_every_rows=25)
+    old = engine.config
+    engine.config = cfg
+    name, d = "durable", 16
+    try:
+        client = M.Milvus()
+        client._engine = engine
+        store = MetaStore(str(tmp_path / "meta.sqlite"))
+        http = create_app(client=client, store=store).test_client()
+        http.get("/deletedb?dbname=" + name)
+        assert "created" in http.get("/createdb?dbname=%s&dimensions=%d" % (name, d)).get_data(as_text=True)
+        rng = np.random.default_rng(11)
+        vecs = [rng.random(d).tolist() for _ in range(60)]
+        for i, v in enumerate(vecs):
+            assert http.put("/insert?dbname=" + name, json={"name": "a%d" % i, "vector": v}).get_data(as_text=True) == "hej"
+        path = M.snapshot_path(cfg.primary_path, name)
+        raw = open(path, "rb").read(72)
+        rows, nsegs = struct.unpack_from("<q", raw, 24)[0], struct.unpack_from("<q", raw, 48)[0]
+        assert (rows, nsegs) == (50, 2) and client.last_snapshot_rows_written == 25     # the second one was incremental
+        assert http.get("/checkintegrity").get_data(as_text=True) == "All ok"
+        engine.drop_table(name)                                  # restart: the table comes back from its snapshot
+        assert client.preload_table(name).OK() and engine.count(name) == 50
+        text = http.get("/checkintegrity").get_data(as_text=True)
+        assert "bad" in text and "60 vector hashes known, 50 vectors stored" in text
+        missing = sorted(O.hash_vector(v) for v in vecs[50:])
+        assert "known but not stored: 10 " + json.dumps(missing) in text
+        # stored vectors answer as before
+        out = json.loads(http.put("/lookup?dbname=" + name, json={"vector": vecs[7]}).get_data())
+        assert out[0]["asset_ids"] == ["a7"] and len(out) == 11
+    finally:
+        engine.config = old
+        if engine.has_table(name):
+            engine.drop_table(name)

@@ -74,3 +74,37 @@ def test_two_rank_sharded_search_on_one_gpu():
         for p in procs:
             assert p.exitcode == 0, "rank exited with %s" % p.exitcode
         assert dict(ret) == {0: True, 1: True}
+
+
+def _run_bench(extra):
+    import json
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--rows", "400000", "--steps", "8", "--warmup", "2",
+           "--cpu-seconds", "0", "--no-secondary"] + extra
+    env = dict(os.environ)
+    for var in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(var, None)
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_with_two_ranks_answers_like_one():
+    """`bench.py --gpus 2` as the multi-GPU driver runs it, rehearsed here with two ranks that share the
+    one GPU (gloo collective): bench.py starts its own rank processes, shards the rows, exchanges the
+    records, merges, and prints one line whose answers are those of the one-rank run (the shard set is the
+    reference's search_resources list, /root/reference/server_config.yaml:43-44)."""
+    one = _run_bench([])
+    two = _run_bench(["--gpus", "2", "--backend", "gloo", "--trace-steps", "4"])
+    assert two["n_gpus"] == 2 and two["config"]["rccl_ranks"] == 2 and two["config"]["rows_per_gpu"] == 200000
+    assert two["config"]["backend"] == "gloo" and two["scaling"] == "strong"
+    assert two["roofline"]["bytes_per_launch"] == 200000 * 768 * 4
+    assert one["n_gpus"] == 1 and one["roofline"]["bytes_per_launch"] == 400000 * 768 * 4
+    assert two["sample_result"] == one["sample_result"]
+    assert two["config"]["exact_fallbacks"] == 0 and two["steps"] == 8
+    tr = two["trace"]
+    for part in ("host_enqueue_us", "device_complete_us"):
+        assert set(tr[part]) >= {"local_search", "collective", "merge"} and tr[part]["steps"] >= 4
+    assert tr["device_complete_us"]["local_search"] > 0 and tr["device_complete_us"]["collective"] > 0

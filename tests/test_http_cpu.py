@@ -177,3 +177,88 @@ def test_create_vectors_tool_is_seeded():
     assert a == b and a[0]["name"] == "v0" and len(a[2]["vector"]) == 8
     assert all(0.0 <= x < 1.0 for x in a[1]["vector"])
     assert list(mod.vectors(8, 1, seed=1)) != a[:1]
+
+
+class CountingClient(RecordingClient):
+    """A stand-in that also answers the two calls /checkintegrity uses to compare both sides."""
+
+    def get_table_row_count(self, name):
+        return Status(), len([1 for n, _, _ in self.inserted if n == name])
+
+    def table_ids(self, name):
+        import numpy as np
+        return Status(), np.array([ids[0] for n, _, ids in self.inserted if n == name], dtype=np.int64)
+
+
+def test_integrity_compares_what_both_sides_hold():
+    client, store = CountingClient(), MetaStore()
+    http = create_app(client=client, store=store).test_client()
+    http.get("/createdb?dbname=t&dimensions=3")
+    vecs = [[0.1 * i, 0.2, 0.3] for i in range(5)]
+    for i, v in enumerate(vecs):
+        http.put("/insert?dbname=t", json={"name": "a%d" % i, "vector": v})
+    http.put("/insert?dbname=t", json={"name": "again", "vector": vecs[0]})      # known hash: not sent again
+    assert len(client.inserted) == 5
+    assert http.get("/checkintegrity").get_data(as_text=True) == "All ok"
+    lost = client.inserted.pop()                                                   # the engine side loses one vector
+    text = http.get("/checkintegrity").get_data(as_text=True)
+    assert "bad" in text and "5 vector hashes known, 4 vectors stored" in text
+    assert "known but not stored: 1 [%d]" % lost[2][0] in text
+
+
+def test_same_vector_from_two_requests_while_the_engine_refuses_the_first():
+    """The second request must not find the hash 'known' while the first one's engine insert is still
+    open: when that insert is refused, neither request may leave the hash behind as known."""
+    import threading
+
+    class SlowRefusingClient(RecordingClient):
+        def __init__(self):
+            super().__init__()
+            self.calls, self.gate = 0, threading.Event()
+
+        def insert(self, name, records, ids):
+            self.calls += 1
+            if self.calls == 1:
+                self.gate.wait(5)
+                return Status(-6, "refused"), []
+            self.inserted.append((name, records, ids))
+            return Status(), ids
+
+    client, store = SlowRefusingClient(), MetaStore()
+    app = create_app(client=client, store=store)
+    app.test_client().get("/createdb?dbname=t&dimensions=3")
+    vec = [0.5, 0.25, 0.125]
+    out = {}
+
+    def put(tag, asset):
+        out[tag] = app.test_client().put("/insert?dbname=t", json={"name": asset, "vector": vec})
+
+    a = threading.Thread(target=put, args=("a", "a1"))
+    a.start()
+    while client.calls == 0:
+        pass
+    b = threading.Thread(target=put, args=("b", "a2"))
+    b.start()
+    b.join(0.3)
+    assert b.is_alive()                    # waits for the first request's verdict instead of answering 'hej'
+    client.gate.set()
+    a.join(5)
+    b.join(5)
+    assert out["a"].status_code == 500 and out["b"].get_data(as_text=True) == "hej"
+    # the second request stored the vector itself; its mapping is the only one
+    assert len(client.inserted) == 1 and store.assets("t", hash_vector(vec)) == ["a2"]
+
+
+def test_engine_insert_that_raises_leaves_no_mapping():
+    class RaisingClient(RecordingClient):
+        def insert(self, name, records, ids):
+            raise RuntimeError("boom")
+
+    store = MetaStore()
+    app = create_app(client=RaisingClient(), store=store)
+    app.config["PROPAGATE_EXCEPTIONS"] = False
+    http = app.test_client()
+    http.get("/createdb?dbname=t&dimensions=3")
+    vec = [1.0, 2.0, 3.0]
+    assert http.put("/insert?dbname=t", json={"name": "x", "vector": vec}).status_code == 500
+    assert store.assets("t", hash_vector(vec)) == []

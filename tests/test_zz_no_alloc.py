@@ -28,7 +28,7 @@ def _both(engine, torch, name, nq, d, k, seed):
     assert np.array_equal(i0, i1)
     assert np.array_equal(s0.view(np.uint32), s1.view(np.uint32))
     assert int(c0.min()) == k
-    return i0
+    return i1, s1
 
 
 def test_noalloc_search_matches_search_dev_twice_in_a_row(engine):
@@ -49,6 +49,29 @@ def test_noalloc_search_matches_search_dev_twice_in_a_row(engine):
         _both(engine, torch, small, 1, 128, 100, seed=22)
         # and the first shape once more
         _both(engine, torch, big, 2, d, 10, seed=23)
+        # directly against the oracle as well (not only against the other entry point)
+        from oracle import oracle as O
+        got_ids, got_sc = _both(engine, torch, small, 2, 128, 10, seed=24)
+        stored = O.prepare_store(O.synth_rows(5, 0, 9_000, 128), O.L2, O.BF16)
+        want = O.search(stored, np.arange(9_000, dtype=np.int64), O.synth_rows(24, 0, 2, 128), 10, O.L2)
+        for qi, (wi, ws) in enumerate(want):
+            assert np.array_equal(got_ids[qi], wi)
+            assert np.array_equal(got_sc[qi].view(np.uint32), ws.view(np.uint32))
+        # what the entry point is for: warm calls take no device memory (nothing allocated, nothing freed)
+        dev = torch.device("cuda", 0)
+        st = torch.cuda.current_stream().cuda_stream
+        q = torch.empty((2, d), dtype=torch.float32, device=dev)
+        engine.synth_fill_dev(q.data_ptr(), 2, d, seed=25, first_row=0, stream=st)
+        o_ids = torch.zeros((2, 10), dtype=torch.int64, device=dev)
+        o_sc = torch.zeros((2, 10), dtype=torch.float32, device=dev)
+        o_cnt = torch.zeros((2,), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        free0, _ = torch.cuda.mem_get_info()
+        for _ in range(5):
+            engine.search_dev_noalloc(big, 2, q.data_ptr(), 10, o_ids.data_ptr(), o_sc.data_ptr(), o_cnt.data_ptr(), st)
+        torch.cuda.synchronize()
+        free1, _ = torch.cuda.mem_get_info()
+        assert free1 == free0
         # beyond the scratch array: refused with a clear error, nothing allocated
         dev = torch.device("cuda", 0)
         nq, k = 64, 10

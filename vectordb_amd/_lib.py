@@ -38,6 +38,7 @@ SIGNATURES = {
     "vdb_synth_fill_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_uint64, C.c_int64, C.c_void_p]),
     "vdb_fetch_rows": (C.c_int, [C.c_char_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "vdb_save_table": (C.c_int, [C.c_char_p, C.c_char_p]),
+    "vdb_save_table_rows": (C.c_int, [C.c_char_p, C.c_char_p, _i64p]),
     "vdb_load_table": (C.c_int, [C.c_char_p, C.c_char_p]),
     "vdb_search": (C.c_int, [C.c_char_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vdb_search_dev": (C.c_int, [C.c_char_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -304,3 +304,14 @@ class ClusterMilvus:
     def preload_table(self, table_name: str, timeout: Optional[int] = None) -> Status:
         with self._lock:
             return self._need() or self._first_failure(self._call_all("preload_table", table_name))
+
+    def table_ids(self, table_name: str) -> Tuple[Status, np.ndarray]:
+        with self._lock:
+            bad = self._need()
+            if bad:
+                return bad, np.empty((0,), dtype=np.int64)
+            replies = self._call_all("table_ids", table_name)
+            st = self._first_failure(replies)
+            if not st.OK():
+                return st, np.empty((0,), dtype=np.int64)
+            return st, np.concatenate([np.asarray(r[2], dtype=np.int64) for r in replies])

@@ -18,6 +18,10 @@ in `raw` so that an existing file loads unchanged.
       fast pass widens by the rounding; tie-heavy data sends more queries to the exact pass)
   engine_config.bf16_mirror (an addition, default true)  fp32 tables keep that mirror (half of the table
       again in HBM); without it batched searches convert the fp32 rows on the fly, at half the speed
+  engine_config.snapshot_every_rows (an addition, default 0 = never)  a table is written to
+      db_config.primary_path whenever this many rows have arrived since its last snapshot; the write is
+      incremental (only the new rows).  The engine the reference talks to persists every insert by itself,
+      and /insert relies on it: a hash the relational side knows is never sent to the engine again
   gpu_resource_config.enable (:41)           must be true: there is no CPU engine
   gpu_resource_config.cache_capacity (:42)   GB of HBM the tables may occupy (0 = no cap)
   gpu_resource_config.search_resources (:43-44)  `gpuN` entries: the shard set; a process binds
@@ -45,6 +49,7 @@ class EngineConfig:
     coalesce_searches: bool = True
     scan_mirror: bool = False
     bf16_mirror: bool = True
+    snapshot_every_rows: int = 0
     gpu_enable: bool = True
     cache_capacity_gb: float = 0.0
     search_resources: List[int] = field(default_factory=lambda: [0])
@@ -85,6 +90,8 @@ def parse_config(doc: Optional[Dict[str, Any]]) -> EngineConfig:
         cfg.scan_mirror = bool(eng["scan_mirror"])
     if "bf16_mirror" in eng:
         cfg.bf16_mirror = bool(eng["bf16_mirror"])
+    if "snapshot_every_rows" in eng and eng["snapshot_every_rows"] is not None:
+        cfg.snapshot_every_rows = max(0, int(eng["snapshot_every_rows"]))
     if "enable" in gpu:
         cfg.gpu_enable = bool(gpu["enable"])
     if "cache_capacity" in gpu and gpu["cache_capacity"] is not None:

@@ -19,7 +19,10 @@
 
 namespace vdb {
 
-typedef std::pair<const void*, int> MergeKey;      // (table, k)
+// (table generation id, k).  The id is handed out once per created table and never reused, so that a
+// table dropped and created again under the same name (or at the same address) while callers wait is
+// another key: its callers are not merged with those of the table that is gone.
+typedef std::pair<uint64_t, int> MergeKey;
 
 // What a request must offer: `MergeKey key; int64_t weight; bool done;` (done is guarded by the
 // merger's mutex; results are handed over by the leader before it sets done).
@@ -28,8 +31,15 @@ class CallMerger {
 public:
     // Blocks until the request has been answered, by this thread (as leader of a batch) or by another
     // caller's batch.  `run(batch)` answers every request of the batch; it runs without the lock held.
+    // If `run` throws (std::bad_alloc of a staging vector, say), `on_throw(batch)` marks every request
+    // of the batch as failed, the key is released and the followers are woken as after a normal run;
+    // the exception does not leave submit() (the callers sit behind a C ABI).
     template <class Run>
     void submit(Req& req, int64_t max_weight, Run run) {
+        submit(req, max_weight, run, [](std::vector<Req*>&) {});
+    }
+    template <class Run, class OnThrow>
+    void submit(Req& req, int64_t max_weight, Run run, OnThrow on_throw) {
         std::vector<Req*> batch;
         {
             std::unique_lock<std::mutex> lk(mu_);
@@ -46,7 +56,11 @@ public:
             }
             pending_.swap(rest);
         }
-        run(batch);
+        try {
+            run(batch);
+        } catch (...) {
+            on_throw(batch);
+        }
         {
             std::lock_guard<std::mutex> lk(mu_);
             for (Req* r : batch) if (r != &req) r->done = true;

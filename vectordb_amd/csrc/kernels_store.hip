@@ -139,6 +139,20 @@ hipError_t launch_append(char* rows, unsigned short* rows16, long long ld16, lon
     return hipSuccess;
 }
 
+// An append collects the largest squared norm of its rows in pending[0] (the append kernel's max_n2
+// argument); it joins the table-wide bound only if no row of the call was refused, so that a refused
+// insert leaves no trace in the bound the certificates (and snapshots) use.
+__global__ void fold_max_kernel(float* __restrict__ table_max, const float* __restrict__ pending,
+                                const int* __restrict__ bad) {
+    if (threadIdx.x == 0 && blockIdx.x == 0 && *bad == 0)
+        atomicMax((unsigned int*)table_max, __float_as_uint(*pending));       // non-negative floats order as integers
+}
+
+hipError_t launch_fold_max(float* table_max, const float* pending, const int* bad, hipStream_t st) {
+    hipLaunchKernelGGL(fold_max_kernel, dim3(1), dim3(64), 0, st, table_max, pending, bad);
+    return hipGetLastError();
+}
+
 // bf16 mirror of stored fp32 rows (tables loaded from a snapshot): one wave per row
 __global__ void __launch_bounds__(256)
 build_mirror_kernel(const char* __restrict__ rows, unsigned short* __restrict__ rows16, long long ld16,

@@ -4,6 +4,7 @@
 #include "host_merge.h"
 
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstdio>
@@ -11,9 +12,13 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <random>
 #include <shared_mutex>
 #include <string>
+#include <string_view>
 #include <vector>
+#include <sys/types.h>
+#include <unistd.h>
 
 namespace vdb {
 
@@ -68,6 +73,9 @@ struct VArray {
 
 struct Table {
     std::string name;
+    uint64_t gen = 0;                    // never reused: what the call mergers key on (host_merge.h)
+    uint64_t uuid = 0;                   // identity across snapshots: drawn at create, restored by load
+    std::mutex snap_mu;                  // one save of this table at a time
     int64_t dim = 0;
     int metric = 0, dtype = 0;
     int m = 0;          // 16-byte units per row
@@ -100,7 +108,8 @@ struct Global {
     bool inited = false;
     int device = 0;
     int n_cu = 256;
-    std::map<std::string, std::shared_ptr<Table>> tables;
+    std::map<std::string, std::shared_ptr<Table>, std::less<>> tables;      // std::less<>: looked up by string_view, no temporary
+    std::atomic<uint64_t> next_gen{1};
     std::vector<std::unique_ptr<Workspace>> free_ws;
     long long* d_counters = nullptr;
     // options
@@ -137,6 +146,8 @@ struct Global {
     hipStream_t chain_last = nullptr;
     // merging of concurrent blocking host searches (see vdb_search and host_merge.h)
     int coalesce_host = 1;
+    std::atomic<int> debug_fail_map{0};  // test hook, see varray_map
+    long long mirrors_dropped = 0;       // tables whose bf16 mirror made room for rows (table_drop_mirror)
 };
 static Global G;
 
@@ -147,6 +158,7 @@ static const size_t NOALLOC_BYTES = (size_t)24 << 20;
 static __device__ __align__(256) unsigned char vdb_noalloc_scratch[NOALLOC_BYTES];
 static const int NOALLOC_MAX_DEV = 64;
 static void* g_noalloc_ptr[NOALLOC_MAX_DEV] = {};
+static std::atomic<int> g_noalloc_busy{0};      // one host call at a time works on the array
 
 static size_t round_up(size_t v, size_t g) { return (v + g - 1) / g * g; }
 
@@ -174,7 +186,7 @@ static int ensure(DevBuf& b, size_t bytes, hipStream_t busy_on, bool fixed = fal
 
 static std::shared_ptr<Table> find_table(const char* name) {
     std::lock_guard<std::mutex> lk(G.mu);
-    auto it = G.tables.find(name);
+    auto it = G.tables.find(std::string_view(name));
     return it == G.tables.end() ? nullptr : it->second;
 }
 
@@ -635,6 +647,8 @@ static hipError_t varray_map(VArray& a, size_t want) {
     acc.location.id = G.device;
     acc.flags = hipMemAccessFlagsProtReadWrite;
     while (a.mapped < want) {
+        // test hook: the n-th chunk asked for from now on is refused as if memory had run out
+        if (G.debug_fail_map > 0 && --G.debug_fail_map == 0) return hipErrorOutOfMemory;
         hipMemGenericAllocationHandle_t h;
         hipError_t e = hipMemCreate(&h, a.chunk, &prop, 0);
         if (e != hipSuccess) return e;
@@ -712,12 +726,15 @@ static int table_alloc(Table& t, int64_t new_cap) {
             if (!parts[i].per_row) continue;
             const size_t before = parts[i].a->mapped;
             const hipError_t e = varray_map(*parts[i].a, want[i]);
+            {
+                // chunks mapped before a failure stay mapped (and are freed with the table): they count
+                std::lock_guard<std::mutex> lk(G.mu);
+                G.table_bytes += parts[i].a->mapped - before;
+            }
             if (e != hipSuccess) {
                 (void)hipGetLastError();
                 return fail(VDB_ENOMEM, std::string("mapping table memory: ") + hipGetErrorString(e));
             }
-            std::lock_guard<std::mutex> lk(G.mu);
-            G.table_bytes += parts[i].a->mapped - before;
         }
         // rows that every mapped array holds
         int64_t cap = INT64_MAX;
@@ -778,6 +795,28 @@ static int table_grow_for(Table& t, int64_t extra) {
     return rc;
 }
 
+// The bf16 mirror of an fp32 table is derived data that only makes batched searches faster.  When
+// rows no longer fit beside it (HBM or gpu_resource_config.cache_capacity), it goes: the rows win, and
+// batched searches over this table convert the fp32 rows on the fly from then on (as with option
+// bf16_mirror 0).  The caller holds the table's exclusive lock, so no search is being enqueued; work
+// already enqueued that reads the mirror is waited for.
+static void table_drop_mirror(Table& t) {
+    if (!t.mirrored()) return;
+    (void)hipDeviceSynchronize();
+    const size_t have = t.a_rows16.mapped;
+    varray_free(t.a_rows16);
+    t.d_rows16 = nullptr;
+    t.ld16 = 0;
+    {
+        std::lock_guard<std::mutex> lk(G.mu);
+        G.table_bytes = G.table_bytes >= have ? G.table_bytes - have : 0;
+        ++G.mirrors_dropped;
+    }
+    std::fprintf(stderr, "vdb: table %s: rows no longer fit beside the bf16 mirror (%zu MiB), which was dropped; "
+                         "batched searches over this table now convert its fp32 rows on the fly\n",
+                 t.name.c_str(), have >> 20);
+}
+
 static void table_free(Table& t) {
     (void)hipDeviceSynchronize();
     size_t have = 0;
@@ -788,7 +827,7 @@ static void table_free(Table& t) {
     t.h_bad = nullptr; t.d_bad = nullptr;
     t.rows.store(0); t.cap.store(0); t.dropped = true;
     std::lock_guard<std::mutex> lk(G.mu);
-    G.table_bytes -= have;
+    G.table_bytes = G.table_bytes >= have ? G.table_bytes - have : 0;
 }
 
 }  // namespace vdb
@@ -932,6 +971,7 @@ int vdb_set_option(const char* key, double value) {
     else if (k == "l2_row_bounds") G.row_bounds = value != 0;
     else if (k == "bf16_mirror") G.bf16_mirror = value != 0;
     else if (k == "virtual_ranges") G.use_vmm = value != 0;
+    else if (k == "debug_fail_map") G.debug_fail_map.store(value > 0 ? (int)value : 0);
     else return fail(VDB_EINVAL, "unknown option: " + k);
     set_scan_tune(G.tune_nt, G.tune_waves, G.tune_bpc, G.tune_contig, G.tune_dyn);
     return VDB_OK;
@@ -947,6 +987,12 @@ int vdb_create_table(const char* name, int64_t dim, int metric, int dtype) {
     if (dtype != VDB_F32 && dtype != VDB_BF16 && dtype != VDB_F16) return fail(VDB_EINVAL, "unknown dtype");
     auto t = std::make_shared<Table>();
     t->name = name; t->dim = dim; t->metric = metric; t->dtype = dtype;
+    t->gen = G.next_gen.fetch_add(1);
+    {
+        std::random_device rd;
+        t->uuid = ((uint64_t)rd() << 32) ^ (uint64_t)rd() ^ ((uint64_t)std::chrono::steady_clock::now().time_since_epoch().count() * 0x9E3779B97F4A7C15ull) ^ t->gen;
+        if (!t->uuid) t->uuid = 1;
+    }
     const int epl = elems_per_unit(dtype);
     t->m = (int)((dim + epl - 1) / epl);
     t->dpad = t->m * epl;
@@ -1042,12 +1088,18 @@ int vdb_reserve(const char* name, int64_t rows) {
         std::shared_lock<std::shared_mutex> tl(t->mu);
         std::lock_guard<std::mutex> il(t->ins_mu);
         if (t->dropped) return fail(VDB_ENOTFOUND, "table was dropped");
-        return table_alloc(*t, rows);
+        const int rc2 = table_alloc(*t, rows);
+        if (rc2 != VDB_ENOMEM || !t->mirrored()) return rc2;
     }
     std::unique_lock<std::shared_mutex> tl(t->mu);
     std::lock_guard<std::mutex> il(t->ins_mu);
     if (t->dropped) return fail(VDB_ENOTFOUND, "table was dropped");
-    return table_alloc(*t, rows);
+    rc = table_alloc(*t, rows);
+    if (rc == VDB_ENOMEM && t->mirrored()) {
+        table_drop_mirror(*t);                       // rows before the mirror: see table_drop_mirror
+        rc = table_alloc(*t, rows);
+    }
+    return rc;
 }
 
 // Appends run one at a time per table and beside searches: the new rows are written behind the
@@ -1062,10 +1114,15 @@ static int insert_locked(Table& t, int64_t n, const float* rows, const long long
     const int64_t base = t.rows.load();
     unsigned short* mirror = t.mirrored() ? t.d_rows16 : nullptr;
     *t.h_bad = 0;
+    // the call's largest row norm is collected beside the table's (d_maxn2[1]) and joins it only when no
+    // row of the call was refused
+    float* const pending = t.d_maxn2 + 1;
     if (synth || !host) {
         hipStream_t st = synth ? G.insert_stream : user_st;
-        VDB_HIP(launch_append(t.d_rows, mirror, t.ld16, t.d_ids, t.d_n2, t.d_maxn2, t.d_bad, base, n, d, t.m, t.dtype,
+        VDB_HIP(hipMemsetAsync(pending, 0, sizeof(float), st));
+        VDB_HIP(launch_append(t.d_rows, mirror, t.ld16, t.d_ids, t.d_n2, pending, t.d_bad, base, n, d, t.m, t.dtype,
                               t.metric, synth ? nullptr : rows, synth ? nullptr : ids, seed, first_row, st));
+        VDB_HIP(launch_fold_max(t.d_maxn2, pending, t.d_bad, st));
         VDB_HIP(hipStreamSynchronize(st));
     } else {
         std::lock_guard<std::mutex> il(G.insert_mu);
@@ -1075,15 +1132,17 @@ static int insert_locked(Table& t, int64_t n, const float* rows, const long long
         if (chunk > n) chunk = n;
         if ((rc = ensure(G.stage_rows, (size_t)chunk * d * sizeof(float), G.insert_stream))) return rc;
         if ((rc = ensure(G.stage_ids, (size_t)chunk * sizeof(long long), G.insert_stream))) return rc;
+        VDB_HIP(hipMemsetAsync(pending, 0, sizeof(float), G.insert_stream));
         for (int64_t i0 = 0; i0 < n; i0 += chunk) {
             const int64_t ni = n - i0 < chunk ? n - i0 : chunk;
             VDB_HIP(hipMemcpyAsync(G.stage_rows.p, rows + (size_t)i0 * d, (size_t)ni * d * sizeof(float),
                                    hipMemcpyHostToDevice, G.insert_stream));
             VDB_HIP(hipMemcpyAsync(G.stage_ids.p, ids + i0, (size_t)ni * sizeof(long long),
                                    hipMemcpyHostToDevice, G.insert_stream));
-            VDB_HIP(launch_append(t.d_rows, mirror, t.ld16, t.d_ids, t.d_n2, t.d_maxn2, t.d_bad, base + i0, ni, d, t.m,
+            VDB_HIP(launch_append(t.d_rows, mirror, t.ld16, t.d_ids, t.d_n2, pending, t.d_bad, base + i0, ni, d, t.m,
                                   t.dtype, t.metric, (const float*)G.stage_rows.p, (const long long*)G.stage_ids.p,
                                   0, 0, G.insert_stream));
+            if (i0 + ni >= n) VDB_HIP(launch_fold_max(t.d_maxn2, pending, t.d_bad, G.insert_stream));
             VDB_HIP(hipStreamSynchronize(G.insert_stream));      // the staging buffers are reused by the next chunk
         }
     }
@@ -1095,16 +1154,31 @@ static int insert_locked(Table& t, int64_t n, const float* rows, const long long
 static int insert_into(Table& t, int64_t n, const float* rows, const long long* ids,
                        bool host, bool synth, uint64_t seed, int64_t first_row, hipStream_t user_st) {
     if (t.vmm) {
-        // searches keep running: nothing they read moves or changes
-        std::shared_lock<std::shared_mutex> tl(t.mu);
+        {
+            // searches keep running: nothing they read moves or changes
+            std::shared_lock<std::shared_mutex> tl(t.mu);
+            std::lock_guard<std::mutex> il(t.ins_mu);
+            if (t.dropped) return fail(VDB_ENOTFOUND, "table was dropped");
+            const int rc = insert_locked(t, n, rows, ids, host, synth, seed, first_row, user_st);
+            if (rc != VDB_ENOMEM || !t.mirrored()) return rc;
+        }
+        // out of memory with a mirror in place: the mirror makes room (exclusive lock: no search may be
+        // reading it), and the insert is tried once more
+        std::unique_lock<std::shared_mutex> tl(t.mu);
         std::lock_guard<std::mutex> il(t.ins_mu);
         if (t.dropped) return fail(VDB_ENOTFOUND, "table was dropped");
+        table_drop_mirror(t);
         return insert_locked(t, n, rows, ids, host, synth, seed, first_row, user_st);
     }
     std::unique_lock<std::shared_mutex> tl(t.mu);
     std::lock_guard<std::mutex> il(t.ins_mu);
     if (t.dropped) return fail(VDB_ENOTFOUND, "table was dropped");
-    return insert_locked(t, n, rows, ids, host, synth, seed, first_row, user_st);
+    int rc = insert_locked(t, n, rows, ids, host, synth, seed, first_row, user_st);
+    if (rc == VDB_ENOMEM && t.mirrored()) {
+        table_drop_mirror(t);
+        rc = insert_locked(t, n, rows, ids, host, synth, seed, first_row, user_st);
+    }
+    return rc;
 }
 
 static int insert_common(const char* name, int64_t n, const float* rows, const long long* ids,
@@ -1167,10 +1241,11 @@ int vdb_insert(const char* name, int64_t n, const float* rows, const int64_t* id
     req.t = find_table(name);
     if (!req.t) return fail(VDB_ENOTFOUND, std::string("no such table: ") + name);
     req.n = n; req.rows = rows; req.ids = (const long long*)ids;
-    req.key = MergeKey(req.t.get(), -1);
+    req.key = MergeKey(req.t->gen, -1);
     req.weight = n;
     static CallMerger<InsReq> merger;
-    merger.submit(req, 4096, [](std::vector<InsReq*>& b) { insert_host_batch(b); });
+    merger.submit(req, 4096, [](std::vector<InsReq*>& b) { insert_host_batch(b); },
+                  [](std::vector<InsReq*>& b) { for (InsReq* r : b) { r->rc = VDB_ENOMEM; r->err = "out of host memory while merging inserts"; } });
     return req.rc == VDB_OK ? VDB_OK : fail(req.rc, req.err);
 }
 
@@ -1212,9 +1287,15 @@ int vdb_fetch_rows(const char* name, int64_t first, int64_t n, float* out_rows, 
 }
 
 // ---------------------------------------------------------------------------------- snapshots
-// File layout (little endian): SnapHeader, then rows[rows * m * 16], ids[rows * 8], n2[rows * 4].
-// The stored rows are already quantised (and normalised for COSINE), so a loaded table is
-// bit-identical to the saved one and searches on it return the same ids and scores.
+// File layout (little endian), version 2: SnapHeader2, then segments back to back, each a SegHeader
+// followed by rows[nrows * m * 16], ids[nrows * 8], n2[nrows * 4].  The segments cover rows
+// [0, header.rows) in order; bytes behind the last segment the header accounts for (an append that
+// did not reach its header update) are ignored.  The stored rows are already quantised (and normalised
+// for COSINE), so a loaded table is bit-identical to the saved one and searches on it return the same
+// ids and scores.  A snapshot carries the identity of the table it was taken from (a random 64-bit
+// value drawn at create time, kept across load): a later save of the same table to the same path
+// appends a segment with the rows that arrived since and rewrites the header last, instead of
+// writing the whole table again.  Version 1 files (SnapHeader, then the three arrays) are still read.
 struct SnapHeader {
     char     magic[8];      // "VDBSNAP1"
     int64_t  dim;
@@ -1222,6 +1303,21 @@ struct SnapHeader {
     int64_t  rows;
     int32_t  m;
     float    max_n2;
+};
+struct SnapHeader2 {
+    char     magic[8];      // "VDBSNAP2"
+    int64_t  dim;
+    int32_t  metric, dtype;
+    int64_t  rows;          // rows the segments that count cover
+    int32_t  m;
+    float    max_n2;
+    uint64_t uuid;          // identity of the table
+    int64_t  nsegs;
+    int64_t  reserved[2];
+};
+struct SegHeader {
+    char     magic[8];      // "VDBSEG01"
+    int64_t  first_row, nrows;
 };
 
 static const size_t SNAP_CHUNK = (size_t)64 << 20;
@@ -1253,37 +1349,110 @@ static int snap_read(FILE* f, char* dev, size_t bytes, void* bounce) {
     return VDB_OK;
 }
 
-int vdb_save_table(const char* name, const char* path) {
+static int snap_sync(FILE* f) {
+    if (fflush(f) != 0 || fsync(fileno(f)) != 0) return fail(VDB_EINVAL, "flush of snapshot file failed");
+    return VDB_OK;
+}
+
+// one segment with rows [first, first + n) of the table at the file's current position
+static int snap_write_segment(FILE* f, const Table& t, int64_t first, int64_t n, void* bounce) {
+    SegHeader sh;
+    std::memset(&sh, 0, sizeof sh);
+    std::memcpy(sh.magic, "VDBSEG01", 8);
+    sh.first_row = first; sh.nrows = n;
+    if (fwrite(&sh, sizeof sh, 1, f) != 1) return fail(VDB_EINVAL, "short write to snapshot file");
+    int rc;
+    const size_t rb = (size_t)t.m * 16;
+    if ((rc = snap_write(f, t.d_rows + (size_t)first * rb, (size_t)n * rb, bounce))) return rc;
+    if ((rc = snap_write(f, (const char*)(t.d_ids + first), (size_t)n * sizeof(long long), bounce))) return rc;
+    if ((rc = snap_write(f, (const char*)(t.d_n2 + first), (size_t)n * sizeof(float), bounce))) return rc;
+    return VDB_OK;
+}
+
+static void snap_fill_header(SnapHeader2& h, const Table& t, int64_t rows, float max_n2, int64_t nsegs) {
+    std::memset(&h, 0, sizeof h);
+    std::memcpy(h.magic, "VDBSNAP2", 8);
+    h.dim = t.dim; h.metric = t.metric; h.dtype = t.dtype; h.rows = rows; h.m = t.m;
+    h.max_n2 = max_n2; h.uuid = t.uuid; h.nsegs = nsegs;
+}
+
+// File offset behind the last segment that header `h` accounts for, or -1 if the segments do not
+// cover [0, h.rows) in order.
+static long long snap_walk(FILE* f, const SnapHeader2& h) {
+    long long off = (long long)sizeof(SnapHeader2);
+    int64_t covered = 0;
+    const long long per_row = (long long)h.m * 16 + 12;
+    while (covered < h.rows) {
+        SegHeader sh;
+        if (fseeko(f, (off_t)off, SEEK_SET) != 0 || fread(&sh, sizeof sh, 1, f) != 1) return -1;
+        if (std::memcmp(sh.magic, "VDBSEG01", 8) != 0 || sh.first_row != covered || sh.nrows < 1 || sh.nrows > h.rows - covered) return -1;
+        off += (long long)sizeof sh + sh.nrows * per_row;
+        covered += sh.nrows;
+    }
+    return off;
+}
+
+static int save_table_impl(const char* name, const char* path, int64_t* rows_written) {
     int rc = enter();
     if (rc) return rc;
     if (!name || !path || !*path) return fail(VDB_EINVAL, "null table name or path");
+    if (rows_written) *rows_written = 0;
     auto t = find_table(name);
     if (!t) return fail(VDB_ENOTFOUND, std::string("no such table: ") + name);
     std::shared_lock<std::shared_mutex> tl(t->mu);
     if (t->dropped) return fail(VDB_ENOTFOUND, "table was dropped");
-    SnapHeader h;
-    std::memset(&h, 0, sizeof h);
-    std::memcpy(h.magic, "VDBSNAP1", 8);
-    h.dim = t->dim; h.metric = t->metric; h.dtype = t->dtype; h.rows = t->rows.load(); h.m = t->m;
-    VDB_HIP(hipMemcpy(&h.max_n2, t->d_maxn2, sizeof(float), hipMemcpyDeviceToHost));
+    std::lock_guard<std::mutex> sl(t->snap_mu);           // one save of a table at a time
+    // the norm bound is read after the row count: it then covers at least the rows that are saved
+    const int64_t rows = t->rows.load(std::memory_order_acquire);
+    float max_n2 = 0.f;
+    VDB_HIP(hipMemcpy(&max_n2, t->d_maxn2, sizeof(float), hipMemcpyDeviceToHost));
     HostPinned hp;
     VDB_HIP(hipHostMalloc(&hp.p, SNAP_CHUNK, hipHostMallocDefault));
+    // a snapshot of this very table under the same name: append what arrived since
+    {
+        FileCloser fc;
+        fc.f = fopen(path, "r+b");
+        SnapHeader2 h;
+        if (fc.f && fread(&h, sizeof h, 1, fc.f) == 1 && std::memcmp(h.magic, "VDBSNAP2", 8) == 0 &&
+            h.uuid == t->uuid && h.dim == t->dim && h.metric == t->metric && h.dtype == t->dtype && h.m == t->m &&
+            h.rows >= 0 && h.rows <= rows) {
+            const long long end = snap_walk(fc.f, h);
+            if (end > 0) {
+                if (h.rows == rows) return VDB_OK;        // nothing new
+                if (fseeko(fc.f, (off_t)end, SEEK_SET) != 0) return fail(VDB_EINVAL, "cannot seek in snapshot file");
+                if ((rc = snap_write_segment(fc.f, *t, h.rows, rows - h.rows, hp.p))) return rc;
+                if (fflush(fc.f) != 0 || ftruncate(fileno(fc.f), ftello(fc.f)) != 0) return fail(VDB_EINVAL, "cannot trim snapshot file");
+                if ((rc = snap_sync(fc.f))) return rc;
+                // the header goes last: until it is rewritten the file reads as the older snapshot
+                SnapHeader2 h2;
+                snap_fill_header(h2, *t, rows, max_n2 > h.max_n2 ? max_n2 : h.max_n2, h.nsegs + 1);
+                if (fseeko(fc.f, 0, SEEK_SET) != 0 || fwrite(&h2, sizeof h2, 1, fc.f) != 1) return fail(VDB_EINVAL, "cannot rewrite snapshot header");
+                if ((rc = snap_sync(fc.f))) return rc;
+                if (rows_written) *rows_written = rows - h.rows;
+                return VDB_OK;
+            }
+        }
+    }
+    // whole table: written under a temporary name, then renamed (a reader never sees half a snapshot)
     const std::string tmp = std::string(path) + ".tmp";
     {
         FileCloser fc;
         fc.f = fopen(tmp.c_str(), "wb");
         if (!fc.f) return fail(VDB_EINVAL, "cannot open snapshot file for writing: " + tmp);
+        SnapHeader2 h;
+        snap_fill_header(h, *t, rows, max_n2, rows > 0 ? 1 : 0);
         if (fwrite(&h, sizeof h, 1, fc.f) != 1) return fail(VDB_EINVAL, "short write to snapshot file");
-        if (h.rows > 0) {
-            if ((rc = snap_write(fc.f, t->d_rows, (size_t)h.rows * t->m * 16, hp.p))) return rc;
-            if ((rc = snap_write(fc.f, (const char*)t->d_ids, (size_t)h.rows * sizeof(long long), hp.p))) return rc;
-            if ((rc = snap_write(fc.f, (const char*)t->d_n2, (size_t)h.rows * sizeof(float), hp.p))) return rc;
-        }
-        if (fflush(fc.f) != 0) return fail(VDB_EINVAL, "flush of snapshot file failed");
+        if (rows > 0 && (rc = snap_write_segment(fc.f, *t, 0, rows, hp.p))) return rc;
+        if ((rc = snap_sync(fc.f))) return rc;
     }
-    // a reader never sees a half-written snapshot under the final name
     if (std::rename(tmp.c_str(), path) != 0) return fail(VDB_EINVAL, std::string("cannot rename snapshot to ") + path);
+    if (rows_written) *rows_written = rows;
     return VDB_OK;
+}
+
+int vdb_save_table(const char* name, const char* path) { return save_table_impl(name, path, nullptr); }
+int vdb_save_table_rows(const char* name, const char* path, int64_t* out_rows_written) {
+    return save_table_impl(name, path, out_rows_written);
 }
 
 int vdb_load_table(const char* name, const char* path) {
@@ -1293,9 +1462,20 @@ int vdb_load_table(const char* name, const char* path) {
     FileCloser fc;
     fc.f = fopen(path, "rb");
     if (!fc.f) return fail(VDB_ENOTFOUND, std::string("cannot open snapshot file: ") + path);
-    SnapHeader h;
-    if (fread(&h, sizeof h, 1, fc.f) != 1 || std::memcmp(h.magic, "VDBSNAP1", 8) != 0)
+    SnapHeader2 h;
+    std::memset(&h, 0, sizeof h);
+    char magic[8];
+    if (fread(magic, 8, 1, fc.f) != 1) return fail(VDB_EINVAL, std::string("not a table snapshot: ") + path);
+    const bool v1 = std::memcmp(magic, "VDBSNAP1", 8) == 0;
+    if (!v1 && std::memcmp(magic, "VDBSNAP2", 8) != 0) return fail(VDB_EINVAL, std::string("not a table snapshot: ") + path);
+    if (fseeko(fc.f, 0, SEEK_SET) != 0) return fail(VDB_EINVAL, "cannot seek in snapshot file");
+    if (v1) {
+        SnapHeader h1;
+        if (fread(&h1, sizeof h1, 1, fc.f) != 1) return fail(VDB_EINVAL, std::string("not a table snapshot: ") + path);
+        h.dim = h1.dim; h.metric = h1.metric; h.dtype = h1.dtype; h.rows = h1.rows; h.m = h1.m; h.max_n2 = h1.max_n2;
+    } else if (fread(&h, sizeof h, 1, fc.f) != 1) {
         return fail(VDB_EINVAL, std::string("not a table snapshot: ") + path);
+    }
     if (h.dim < 1 || h.dim > 16384 || h.rows < 0 ||
         (h.metric != VDB_METRIC_L2 && h.metric != VDB_METRIC_IP && h.metric != VDB_METRIC_COSINE) ||
         (h.dtype != VDB_F32 && h.dtype != VDB_BF16 && h.dtype != VDB_F16))
@@ -1304,11 +1484,15 @@ int vdb_load_table(const char* name, const char* path) {
     if (h.m != (int)((h.dim + epl - 1) / epl)) return fail(VDB_EINVAL, "snapshot row stride does not match its dimension");
     if (!(h.max_n2 >= 0.0f)) return fail(VDB_EINVAL, "snapshot header holds values out of range");
     // the payload must be as long as the header promises before any device memory is taken
-    const long long payload = (long long)h.rows * ((long long)h.m * 16 + 12);
-    if (fseek(fc.f, 0, SEEK_END) != 0) return fail(VDB_EINVAL, "cannot seek in snapshot file");
-    const long long fsize = ftell(fc.f);
-    if (fsize != (long long)sizeof h + payload) return fail(VDB_EINVAL, "snapshot file length does not match its header");
-    if (fseek(fc.f, (long)sizeof h, SEEK_SET) != 0) return fail(VDB_EINVAL, "cannot seek in snapshot file");
+    if (fseeko(fc.f, 0, SEEK_END) != 0) return fail(VDB_EINVAL, "cannot seek in snapshot file");
+    const long long fsize = (long long)ftello(fc.f);
+    if (v1) {
+        const long long payload = (long long)h.rows * ((long long)h.m * 16 + 12);
+        if (fsize != (long long)sizeof(SnapHeader) + payload) return fail(VDB_EINVAL, "snapshot file length does not match its header");
+    } else {
+        const long long end = snap_walk(fc.f, h);
+        if (end < 0 || end > fsize) return fail(VDB_EINVAL, "snapshot file length does not match its header");
+    }
 
     if ((rc = vdb_create_table(name, h.dim, h.metric, h.dtype))) return rc;
     auto t = find_table(name);
@@ -1316,14 +1500,32 @@ int vdb_load_table(const char* name, const char* path) {
     {
         std::unique_lock<std::shared_mutex> tl(t->mu);
         std::lock_guard<std::mutex> il(t->ins_mu);
+        if (!v1) t->uuid = h.uuid;                    // later saves of the loaded table extend the same file
         if (h.rows > 0) {
             HostPinned hp;
             rc = table_alloc(*t, h.rows);
+            if (rc == VDB_ENOMEM && t->mirrored()) { table_drop_mirror(*t); rc = table_alloc(*t, h.rows); }
             if (!rc && hipHostMalloc(&hp.p, SNAP_CHUNK, hipHostMallocDefault) != hipSuccess)
                 rc = fail(VDB_ENOMEM, "cannot allocate the host staging buffer");
-            if (!rc) rc = snap_read(fc.f, t->d_rows, (size_t)h.rows * h.m * 16, hp.p);
-            if (!rc) rc = snap_read(fc.f, (char*)t->d_ids, (size_t)h.rows * sizeof(long long), hp.p);
-            if (!rc) rc = snap_read(fc.f, (char*)t->d_n2, (size_t)h.rows * sizeof(float), hp.p);
+            const size_t rb = (size_t)h.m * 16;
+            if (!rc && v1) {
+                if (fseeko(fc.f, (off_t)sizeof(SnapHeader), SEEK_SET) != 0) rc = fail(VDB_EINVAL, "cannot seek in snapshot file");
+                if (!rc) rc = snap_read(fc.f, t->d_rows, (size_t)h.rows * rb, hp.p);
+                if (!rc) rc = snap_read(fc.f, (char*)t->d_ids, (size_t)h.rows * sizeof(long long), hp.p);
+                if (!rc) rc = snap_read(fc.f, (char*)t->d_n2, (size_t)h.rows * sizeof(float), hp.p);
+            } else if (!rc) {
+                if (fseeko(fc.f, (off_t)sizeof(SnapHeader2), SEEK_SET) != 0) rc = fail(VDB_EINVAL, "cannot seek in snapshot file");
+                int64_t covered = 0;
+                while (!rc && covered < h.rows) {
+                    SegHeader sh;
+                    if (fread(&sh, sizeof sh, 1, fc.f) != 1 || std::memcmp(sh.magic, "VDBSEG01", 8) != 0 ||
+                        sh.first_row != covered || sh.nrows < 1 || sh.nrows > h.rows - covered) { rc = fail(VDB_EINVAL, "snapshot segment is damaged"); break; }
+                    rc = snap_read(fc.f, t->d_rows + (size_t)covered * rb, (size_t)sh.nrows * rb, hp.p);
+                    if (!rc) rc = snap_read(fc.f, (char*)(t->d_ids + covered), (size_t)sh.nrows * sizeof(long long), hp.p);
+                    if (!rc) rc = snap_read(fc.f, (char*)(t->d_n2 + covered), (size_t)sh.nrows * sizeof(float), hp.p);
+                    covered += sh.nrows;
+                }
+            }
             if (!rc && t->mirrored()) {
                 // the bf16 image of the rows is derived data: rebuilt, not stored
                 hipError_t e = launch_build_mirror(t->d_rows, t->d_rows16, t->ld16, 0, h.rows, t->m, nullptr);
@@ -1371,10 +1573,13 @@ int vdb_search_dev(const char* name, int64_t nq, const float* queries_dev, int k
     return rc;
 }
 
-// Same search as vdb_search_dev for callers that must not allocate device memory (code under HIP graph
-// capture, tight serving loops): every intermediate buffer is carved from the 24 MiB scratch array
-// above, always by the per-query scan (no batched path), nothing is created, allocated or freed.
-// All calls on one GPU share the array: calls that overlap in time race.
+// Same search as vdb_search_dev for callers that must not allocate device memory (tight serving loops,
+// harnesses that forbid it): every intermediate buffer is carved from the 24 MiB scratch array above,
+// always by the per-query scan (no batched path), nothing is created, allocated or freed.
+// All calls on one GPU share the array.  A call that arrives while another thread is inside the entry
+// point is refused (VDB_ESTATE); calls enqueued one after the other on one stream are kept apart by
+// stream order; calls on different streams must be ordered by the caller (the work of a call that has
+// returned may still be running).
 int vdb_search_dev_noalloc(const char* name, int64_t nq, const float* queries_dev, int k,
                            int64_t* out_ids_dev, float* out_scores_dev, int32_t* out_counts_dev, void* stream) {
     int rc = enter();
@@ -1385,10 +1590,16 @@ int vdb_search_dev_noalloc(const char* name, int64_t nq, const float* queries_de
     if (nq == 0) return VDB_OK;
     char* base = G.device < NOALLOC_MAX_DEV ? (char*)g_noalloc_ptr[G.device] : nullptr;
     if (!base) return fail(VDB_ESTATE, "no scratch array on this device");
+    struct Busy {
+        bool mine = false;
+        Busy() { int expect = 0; mine = g_noalloc_busy.compare_exchange_strong(expect, 1); }
+        ~Busy() { if (mine) g_noalloc_busy.store(0); }
+    } busy;
+    if (!busy.mine) return fail(VDB_ESTATE, "vdb_search_dev_noalloc: another call is using the scratch array");
     std::shared_lock<std::shared_mutex> tl(t->mu);
     if (t->dropped) return fail(VDB_ENOTFOUND, "table was dropped");
     // sizes as search_scan_path asks for them, for the table as it is now
-    TableView tv;
+    TableView tv{};
     tv.rows = t->d_rows; tv.n = t->rows.load(std::memory_order_acquire); tv.d = (int)t->dim; tv.m = t->m;
     tv.dt = t->dtype; tv.metric = t->metric;
     SelGeom g = sel_geom(k);
@@ -1542,14 +1753,19 @@ int vdb_search(const char* name, int64_t nq, const float* queries, int k,
     req.out_ids = out_ids; req.out_scores = out_scores; req.out_counts = out_counts;
     std::vector<HostReq*> batch;
     if (!G.coalesce_host) {
-        batch.push_back(&req);
-        search_host_batch(batch);
+        try {
+            batch.push_back(&req);
+            search_host_batch(batch);
+        } catch (...) {
+            return fail(VDB_ENOMEM, "out of host memory");
+        }
         return req.rc;
     }
-    req.key = MergeKey(req.t.get(), k);
+    req.key = MergeKey(req.t->gen, k);
     req.weight = nq;
     static CallMerger<HostReq> merger;       // calls with different (table, k) never wait for each other
-    merger.submit(req, 1024, [](std::vector<HostReq*>& b) { search_host_batch(b); });
+    merger.submit(req, 1024, [](std::vector<HostReq*>& b) { search_host_batch(b); },
+                  [](std::vector<HostReq*>& b) { for (HostReq* r : b) { r->rc = VDB_ENOMEM; r->err = "out of host memory while merging searches"; } });
     return req.rc == VDB_OK ? VDB_OK : fail(req.rc, req.err);
 }
 

@@ -175,6 +175,9 @@ hipError_t launch_append(char* rows, unsigned short* rows16, long long ld16, lon
                          const float* raw, const long long* raw_ids,
                          uint64_t seed, long long synth_first_row, hipStream_t st);
 
+// table_max = max(table_max, *pending) unless *bad is set (see fold_max_kernel)
+hipError_t launch_fold_max(float* table_max, const float* pending, const int* bad, hipStream_t st);
+
 // (re)builds the bf16 mirror of rows [row0, row0 + n) of an fp32 table from the stored rows
 hipError_t launch_build_mirror(const char* rows, unsigned short* rows16, long long ld16, long long row0,
                                long long n, int m, hipStream_t st);

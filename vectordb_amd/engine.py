@@ -102,8 +102,18 @@ class Engine:
         return rows, ids
 
     # ---- snapshots
-    def save_table(self, name: str, path: str) -> None:
-        check(self.lib.vdb_save_table(_name(name), os.fsencode(path)))
+    def save_table(self, name: str, path: str) -> int:
+        """Writes the table to `path`, or appends the rows that arrived since the last save of the same
+        table to that path.  Returns the number of rows written."""
+        written = C.c_int64(0)
+        check(self.lib.vdb_save_table_rows(_name(name), os.fsencode(path), C.byref(written)))
+        return int(written.value)
+
+    def fetch_ids(self, name: str, first: int, n: int) -> np.ndarray:
+        ids = np.empty((n,), dtype=np.int64)
+        if n:
+            check(self.lib.vdb_fetch_rows(_name(name), int(first), int(n), None, ids.ctypes.data))
+        return ids
 
     def load_table(self, name: str, path: str) -> None:
         check(self.lib.vdb_load_table(_name(name), os.fsencode(path)))

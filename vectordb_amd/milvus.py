@@ -114,6 +114,8 @@ def _preload(engine: Engine, cfg: EngineConfig) -> List[str]:
         path = snapshot_path(cfg.primary_path, name)
         if os.path.exists(path) and not engine.has_table(name):
             engine.load_table(name, path)
+            with _snap_lock:
+                _snap_rows[name] = engine.count(name)
             loaded.append(name)
     return loaded
 
@@ -133,10 +135,16 @@ def _get_engine(config: Optional[EngineConfig]) -> Engine:
         return _engine
 
 
+# rows each table held at its last snapshot (process-wide, like the engine), for snapshot_every_rows
+_snap_lock = threading.Lock()
+_snap_rows: Dict[str, int] = {}
+
+
 class Milvus:
     def __init__(self, config: Optional[EngineConfig] = None):
         self._config = config
         self._engine: Optional[Engine] = None
+        self.last_snapshot_rows_written = 0
 
     # -- connection -------------------------------------------------------------------------
     def connect(self, host: Optional[str] = None, port: Optional[str] = None, uri: Optional[str] = None,
@@ -203,6 +211,8 @@ class Milvus:
         try:
             eng = self._eng()
             eng.drop_table(table_name)
+            with _snap_lock:
+                _snap_rows.pop(table_name, None)
             # a dropped table must not come back at the next start
             try:
                 os.remove(snapshot_path(eng.config.primary_path, table_name))
@@ -232,14 +242,44 @@ class Milvus:
     # -- snapshots -------------------------------------------------------------------------
     def snapshot(self, table_name: str) -> Status:
         """Write `table_name` to db_config.primary_path so that a restarted process can preload it
-        (the external engine persisted every insert to that directory by itself)."""
+        (the external engine persisted every insert to that directory by itself).  A table that already
+        has a snapshot there gets only its new rows appended; `last_snapshot_rows_written` says how many."""
         try:
             eng = self._eng()
             os.makedirs(eng.config.primary_path, exist_ok=True)
-            eng.save_table(table_name, snapshot_path(eng.config.primary_path, table_name))
+            rows = eng.count(table_name)
+            self.last_snapshot_rows_written = eng.save_table(table_name, snapshot_path(eng.config.primary_path, table_name))
+            with _snap_lock:
+                _snap_rows[table_name] = max(rows, _snap_rows.get(table_name, 0))
             return Status()
         except Exception as exc:
             return self._status(exc)
+
+    def _maybe_snapshot(self, table_name: str) -> None:
+        """engine_config.snapshot_every_rows: called after an insert went through."""
+        eng = self._eng()
+        every = int(getattr(eng.config, "snapshot_every_rows", 0) or 0)
+        if every <= 0:
+            return
+        rows = eng.count(table_name)
+        with _snap_lock:
+            due = rows - _snap_rows.get(table_name, 0) >= every
+            if due:
+                _snap_rows[table_name] = rows          # one caller writes; the others go on
+        if due:
+            st = self.snapshot(table_name)
+            if not st.OK():
+                print("snapshot of %s failed: %s" % (table_name, st.message))
+
+    def table_ids(self, table_name: str) -> Tuple[Status, np.ndarray]:
+        """ids of every stored row (what /checkintegrity compares with the relational side)."""
+        try:
+            eng = self._eng()
+            n = eng.count(table_name)
+            parts = [eng.fetch_ids(table_name, i, min(1 << 22, n - i)) for i in range(0, n, 1 << 22)]
+            return Status(), (np.concatenate(parts) if parts else np.empty((0,), dtype=np.int64))
+        except Exception as exc:
+            return self._status(exc), np.empty((0,), dtype=np.int64)
 
     def preload_table(self, table_name: str, timeout: Optional[int] = None) -> Status:
         """Bring `table_name` into HBM from its snapshot unless it is already resident."""
@@ -247,6 +287,8 @@ class Milvus:
             eng = self._eng()
             if not eng.has_table(table_name):
                 eng.load_table(table_name, snapshot_path(eng.config.primary_path, table_name))
+                with _snap_lock:
+                    _snap_rows[table_name] = eng.count(table_name)
             return Status()
         except Exception as exc:
             return self._status(exc)
@@ -264,6 +306,7 @@ class Milvus:
                 base = eng.count(table_name)
                 ids = list(range(base, base + rows.shape[0]))
             eng.insert(table_name, rows, np.asarray(ids, dtype=np.int64))
+            self._maybe_snapshot(table_name)
             return Status(), [int(i) for i in ids]
         except Exception as exc:
             return self._status(exc), []

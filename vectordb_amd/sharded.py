@@ -71,11 +71,25 @@ class ShardedSearcher:
         self.out = torch.zeros(nb, dtype=torch.uint8, device=device)
         self.rec_views = record_views(self.rec, nq, k)
         self.out_views = record_views(self.out, nq, k)
+        # when a list: one (local search, collective, merge) triple of host microseconds per call, the time
+        # each of the three steps took to ENQUEUE (with `trace_sync` set, to complete on the device)
+        self.trace: Optional[list] = None
+        self.trace_sync = False
+
+    def _mark(self) -> int:
+        import time
+        if self.trace_sync and self.rec.is_cuda:
+            torch.cuda.current_stream().synchronize()
+        return time.perf_counter_ns()
 
     def search(self, queries: torch.Tensor) -> RecordViews:
         """queries [nq, d] fp32 on this rank's device, identical on every rank."""
+        t0 = self._mark() if self.trace is not None else 0
         self.local_search(queries, self.rec_views)
+        t1 = self._mark() if self.trace is not None else 0
         if self.world == 1:
+            if self.trace is not None:
+                self.trace.append(((t1 - t0) / 1e3, 0.0, 0.0))
             return self.rec_views
         if self.rec.is_cuda and dist.get_backend(self.group) == "gloo":
             # rehearsal of the N > 1 path without RCCL (ranks sharing one GPU): gloo moves host
@@ -85,7 +99,11 @@ class ShardedSearcher:
             self.gathered.copy_(host)
         else:
             dist.all_gather_into_tensor(self.gathered, self.rec, group=self.group)
+        t2 = self._mark() if self.trace is not None else 0
         self.merge(self.gathered, self.world, self.out_views)
+        if self.trace is not None:
+            t3 = self._mark()
+            self.trace.append(((t1 - t0) / 1e3, (t2 - t1) / 1e3, (t3 - t2) / 1e3))
         return self.out_views
 
 
