@@ -130,6 +130,14 @@ int vdb_reserve(const char* name, int64_t rows);
 int vdb_table_info(const char* name, int64_t* dim, int* metric, int* dtype,
                    int64_t* rows, int64_t* capacity, int64_t* row_stride_bytes);
 
+/* HBM bytes the bf16 mirror of an fp32 table occupies at the moment (see option "bf16_mirror"); 0 for
+ * 16-bit tables, for tables created without one, and for tables whose mirror was dropped: when rows
+ * no longer fit beside the mirror (HBM exhausted, or gpu_resource_config.cache_capacity,
+ * /root/reference/server_config.yaml:42), an insert, reserve or load drops the mirror of that table
+ * (a notice goes to stderr) and goes on, instead of failing with VDB_ENOMEM; batched searches over the
+ * table then convert its fp32 rows on the fly, with the same exact answers. */
+int vdb_table_mirror_bytes(const char* name, int64_t* out_bytes);
+
 /* ---- append: replaces insert(table, records=[vec], ids=[id]) (app.py:315-325) ------------- */
 /* rows: [n, dim] row-major fp32 on the host; ids: [n] caller-supplied signed 64-bit ids.
  * COSINE tables normalise each row on the device while appending. */

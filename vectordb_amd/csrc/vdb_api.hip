@@ -1078,6 +1078,16 @@ int vdb_table_info(const char* name, int64_t* dim, int* metric, int* dtype, int6
     return VDB_OK;
 }
 
+int vdb_table_mirror_bytes(const char* name, int64_t* out_bytes) {
+    if (!G.inited) return fail(VDB_ESTATE, "vdb_init has not been called");
+    if (!name || !out_bytes) return fail(VDB_EINVAL, "null argument");
+    auto t = find_table(name);
+    if (!t) return fail(VDB_ENOTFOUND, std::string("no such table: ") + name);
+    std::shared_lock<std::shared_mutex> tl(t->mu);
+    *out_bytes = t->mirrored() ? (int64_t)t->a_rows16.mapped : 0;
+    return VDB_OK;
+}
+
 int vdb_reserve(const char* name, int64_t rows) {
     int rc = enter();
     if (rc) return rc;

@@ -70,6 +70,12 @@ class Engine:
         return dict(dim=dim.value, metric=metric.value, dtype=dtype.value, rows=rows.value,
                     capacity=cap.value, row_stride_bytes=stride.value)
 
+    def mirror_bytes(self, name: str) -> int:
+        """HBM bytes of the table's bf16 mirror (0: none, or dropped to make room for rows)."""
+        out = C.c_int64(0)
+        check(self.lib.vdb_table_mirror_bytes(_name(name), C.byref(out)))
+        return int(out.value)
+
     # ---- append
     def insert(self, name: str, rows, ids) -> None:
         rows = np.ascontiguousarray(rows, dtype=np.float32)
