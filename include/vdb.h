@@ -106,6 +106,9 @@ int vdb_shutdown(void);
  * default 0).  The three apply to tables created, and searches started, after the call.
  * Exactness layer: "l2_row_bounds" (1 = L2 keys carry the error term of their own row, so rows of very
  * large norm do not send other queries to the exact pass (default); 0 = table-wide norm bound),
+ * "ip_outliers" (1 = IP tables keep rows whose norm is 8 to 11 times the typical one, up to 1024 of them, on
+ * a side list: the batched path takes its error bound over the other rows and re-scores the listed rows
+ * canonically for every query (default); 0 = table-wide bound; applies to rows inserted after the call),
  * "force_exact" (1 = every query is answered by the exact pass; for measuring it).
  * Host calls: "coalesce_host" (1 = blocking vdb_search calls that arrive from other threads while one
  * is running are merged into one batched search, see vdb_search, and vdb_insert calls of up to 256 rows

@@ -1016,3 +1016,82 @@ def test_fp32_table_grows_past_two_thirds_of_the_hbm(engine, table_name):
         ssc = OC.scores(O.prepare_store(OC.synth_rows(0, s0, 100_000, d), O.COSINE, O.F32), qp, O.COSINE)
         better = np.nonzero(ssc > sc[j, k - 1])[0] + s0
         assert set(better.tolist()) <= set(ids[j].tolist())
+
+
+def _rows_with_long_orthogonal_ones(seed, n, d, q, n_long, factor):
+    """Synthetic rows; n_long of them are `factor` times longer than the rest and orthogonal to every
+    query (to fp32 rounding): their true scores are about zero, their bf16 fast keys are anything."""
+    rows = cases.make_rows("synth", seed, n, d)
+    rng = np.random.default_rng(seed)
+    basis, _ = np.linalg.qr(q.astype(np.float64).T)                  # [d, nq] orthonormal basis of the queries' span
+    where = rng.choice(n, size=n_long, replace=False)
+    for r in where:
+        v = rng.standard_normal(d)
+        v -= basis @ (basis.T @ v)
+        rows[r] = (v / np.linalg.norm(v) * np.sqrt(d) * factor).astype(np.float32)
+    return rows, np.sort(where)
+
+
+@pytest.mark.parametrize("nq", [3, 40, 150])
+def test_ip_rows_far_longer_than_the_rest_stay_off_the_exact_pass(engine, table_name, nq):
+    """IP on raw vectors is the reference's metric (/root/reference/app.py:22,141).  A few rows a hundred
+    times longer than the rest and orthogonal to the queries put 2^-8 of their norm into the table-wide
+    bound of the batched path, which sends every query to the exact pass; kept on the side list (and
+    re-scored canonically for every query) they cost nothing.  Same exact answers either way."""
+    n, d = 70_000, 256                                   # 65536 rows or more: batches take the batched path
+    q = cases.make_queries("synth", 71, 150, d, None)
+    rows, where = _rows_with_long_orthogonal_ones(71, n, d, q, 12, 100.0)
+    ids = cases.make_ids("hash", 71, n)
+    fallbacks = {}
+    try:
+        for on in (1, 0):
+            engine.set_option("ip_outliers", on)
+            name = "%s_%d" % (table_name, on)
+            if engine.has_table(name):
+                engine.drop_table(name)
+            # several inserts: the list is extended as rows arrive
+            engine.create_table(name, d, _lib.METRIC_IP, _lib.F32)
+            for lo in range(0, n, 25_000):
+                engine.insert(name, rows[lo:lo + 25_000], ids[lo:lo + 25_000])
+            stored = O.prepare_store(rows, O.IP, O.F32)
+            before = engine.stats()
+            _check(engine, name, stored, ids, q[:nq], 10, O.IP)
+            fallbacks[on] = engine.stats()[1] - before[1]
+            engine.drop_table(name)
+        assert fallbacks[1] == 0, fallbacks
+        if nq >= 40:
+            assert fallbacks[0] > 0, fallbacks               # the case the list exists for
+    finally:
+        engine.set_option("ip_outliers", 1)
+        for on in (1, 0):
+            if engine.has_table("%s_%d" % (table_name, on)):
+                engine.drop_table("%s_%d" % (table_name, on))
+
+
+def test_long_rows_that_are_the_best_hits_are_still_found(engine, table_name, tmp_path):
+    """Rows on the side list are answers like any other: long rows aligned with a query come first, also
+    after the table went through a snapshot (the list is rebuilt on load), and a row that arrives later
+    and is longer still joins the list."""
+    n, d, nq = 70_000, 128, 50
+    q = cases.make_queries("synth", 81, nq, d, None)
+    rows = cases.make_rows("synth", 81, n, d)
+    for j, r in enumerate((5, 777, 60_001)):
+        rows[r] = q[j] * 40.0                                            # long and parallel to query j
+    rows[12_345] *= 60.0                                                 # long, unrelated
+    ids = cases.make_ids("hash", 81, n)
+    stored = _load(engine, table_name, rows, ids, O.IP, _lib.F32)
+    before = engine.stats()
+    _check(engine, table_name, stored, ids, q, 10, O.IP)
+    got_ids, _, _ = engine.search(table_name, q[:3], 10)
+    assert [int(got_ids[j, 0]) for j in range(3)] == [int(ids[5]), int(ids[777]), int(ids[60_001])]
+    path = str(tmp_path / "long.vdbsnap")
+    engine.save_table(table_name, path)
+    engine.drop_table(table_name)
+    engine.load_table(table_name, path)
+    _check(engine, table_name, stored, ids, q, 10, O.IP)
+    late = (q[7:8] * 90.0).astype(np.float32)
+    engine.insert(table_name, late, np.array([2 ** 40], dtype=np.int64))
+    stored2 = np.concatenate([stored, O.prepare_store(late, O.IP, O.F32)])
+    ids2 = np.concatenate([ids, np.array([2 ** 40], dtype=np.int64)])
+    _check(engine, table_name, stored2, ids2, q, 10, O.IP)
+    assert engine.stats()[1] == before[1]

@@ -245,7 +245,7 @@ def test_mapping_that_fails_part_way_keeps_the_budget_count_right(engine, tmp_pa
     if engine.has_table(name):
         engine.drop_table(name)
     try:
-        engine.create_table(name, 64, _lib.METRIC_IP, _lib.F32)
+        engine.create_table(name, 64, _lib.METRIC_IP, _lib.BF16)     # no mirror to give up: the failure reaches the caller
         engine.set_option("debug_fail_map", 2)               # the second chunk asked for is refused
         with pytest.raises(VdbError) as e:
             engine.insert_synthetic(name, 2000, seed=1, first_row=0)

@@ -224,7 +224,8 @@ __device__ __forceinline__ float fkey_inv_g(uint32_t k) {
 __global__ void __launch_bounds__(1024)
 kth_threshold_kernel(const float* __restrict__ cand_s, long long stride, const int* __restrict__ cnt,
                      long long count_all, int cap, int K, const float* __restrict__ thr_in,
-                     float* __restrict__ thr_out) {
+                     float* __restrict__ thr_out, const float* __restrict__ n2, float out_limit, long long nrows,
+                     const long long* __restrict__ cand_t) {
     __shared__ int hist[256];
     __shared__ int ctl[8];
     const int q = blockIdx.x;
@@ -232,6 +233,7 @@ kth_threshold_kernel(const float* __restrict__ cand_s, long long stride, const i
     long long count = cnt ? (long long)cnt[q] : count_all;
     if (cnt && count > cap) count = cap;
     const float* gs = cand_s + (size_t)q * stride;
+    const long long* gt = cand_t ? cand_t + (size_t)q * stride : nullptr;
     const float tin = thr_in ? thr_in[q] : -__builtin_huge_valf();
     uint32_t prefix = 0;
     int need = K;
@@ -242,7 +244,12 @@ kth_threshold_kernel(const float* __restrict__ cand_s, long long stride, const i
         const int shift = 24 - 8 * pass;
         for (long long i0 = 0; i0 < count; i0 += nth) {
             const long long i = i0 + tid;
-            const float v = (i < count) ? gs[i] : -__builtin_huge_valf();
+            float v = (i < count) ? gs[i] : -__builtin_huge_valf();
+            if (n2 != nullptr && i < count) {
+                // rows on the table's list of long rows do not take part (every query re-scores them anyway)
+                const long long r = gt ? gt[i] : i;
+                if (r >= 0 && r < nrows && n2[r] > out_limit) v = -__builtin_huge_valf();
+            }
             const uint32_t key = fkey_g(v);
             const bool act = (v > -__builtin_huge_valf()) && (pass == 0 || (key >> (shift + 8)) == prefix);
             // aggregate equal bins of a wave into one LDS atomic
@@ -288,9 +295,13 @@ kth_threshold_kernel(const float* __restrict__ cand_s, long long stride, const i
 }
 
 hipError_t launch_kth_threshold(const float* cand_s, long long stride, const int* cnt, long long count_all,
-                                int cap, int K, const float* thr_in, float* thr_out, int nq, hipStream_t st) {
+                                int cap, int K, const float* thr_in, float* thr_out, int nq, hipStream_t st,
+                                const TableView* t, const long long* cand_t) {
+    const bool side = t != nullptr && t->n_out > 0;
     hipLaunchKernelGGL(kth_threshold_kernel, dim3((unsigned)nq), dim3(1024), 0, st,
-                       cand_s, stride, cnt, count_all, cap, K, thr_in, thr_out);
+                       cand_s, stride, cnt, count_all, cap, K, thr_in, thr_out,
+                       side ? t->n2 : (const float*)nullptr, side ? t->out_limit : 0.f, side ? t->n : 0LL,
+                       side ? cand_t : (const long long*)nullptr);
     return hipGetLastError();
 }
 

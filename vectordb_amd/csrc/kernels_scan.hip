@@ -1130,13 +1130,19 @@ finalize_band_kernel(FinParams p) {
             band = L - D - 4.0 * u * fabs(L) - 1e-37;
             if (!(band > (double)p.flat_tau[qi])) ok = false;
         }
-    } else if (ok) {
-        const bool all = select_kth([&](long long i, int) { return gs[i]; }, M, p.k, hist, ctl, thr, need);
+    }
+    // A few rows far longer than the rest (IP tables): the bound below is taken over the rest, the long
+    // rows' fast keys are left out (their own error bars dwarf the scores), and all of them are re-scored
+    // canonically with the band, whatever their fast keys say.
+    const bool side = !l2 && p.t.n_out > 0;
+    auto long_row = [&](long long i) -> bool { return side && p.t.n2[gt[i]] > p.t.out_limit; };
+    if (ok && !rowb) {
+        const bool all = select_kth([&](long long i, int) { return long_row(i) ? neg_inf() : gs[i]; }, M, p.k, hist, ctl, thr, need);
         if (all) ok = false;                            // fewer than k usable keys
     }
     if (ok && !rowb) {
         const double fk = (double)fkey_inv(thr);
-        const double bx = sqrt((double)(*p.t.max_n2)) * (1.0 + 1e-6);
+        const double bx = sqrt((double)(side ? p.t.max_rest : *p.t.max_n2)) * (1.0 + 1e-6);
         const double bq = (double)p.qinfo[qi].bq;
         const double u = 5.9604644775390625e-08;        // 2^-24
         const double dd = (double)p.t.d * p.dd_mult + 16.0;
@@ -1153,7 +1159,7 @@ finalize_band_kernel(FinParams p) {
     if (ok) {
         for (long long i0 = 0; i0 < M; i0 += nth) {
             const long long i = i0 + tid;
-            const bool in = i < M && (double)gs[i] >= band;
+            const bool in = i < M && (double)gs[i] >= band && !long_row(i);
             const unsigned long long m = __ballot(in);
             if (m) {
                 int base = 0;
@@ -1161,6 +1167,16 @@ finalize_band_kernel(FinParams p) {
                 base = __shfl(base, 0);
                 const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
                 if (in && pos < BAND_CAP) ST[pos] = gt[i];
+            }
+        }
+        if (side) {
+            // the rows on the list, as far as this search sees them (rows of an insert still under way do not count)
+            for (int j = tid; j < p.t.n_out; j += nth) {
+                const long long r = p.t.outliers[j];
+                if (r >= 0 && r < p.t.n) {
+                    const int pos = atomicAdd(&ctl[5], 1);
+                    if (pos < BAND_CAP) ST[pos] = r;
+                }
             }
         }
         __syncthreads();

@@ -142,14 +142,66 @@ hipError_t launch_append(char* rows, unsigned short* rows16, long long ld16, lon
 // An append collects the largest squared norm of its rows in pending[0] (the append kernel's max_n2
 // argument); it joins the table-wide bound only if no row of the call was refused, so that a refused
 // insert leaves no trace in the bound the certificates (and snapshots) use.
+// The table's bound after the fold is also left in bad[1] (host-visible memory) for the host to read.
 __global__ void fold_max_kernel(float* __restrict__ table_max, const float* __restrict__ pending,
-                                const int* __restrict__ bad) {
-    if (threadIdx.x == 0 && blockIdx.x == 0 && *bad == 0)
-        atomicMax((unsigned int*)table_max, __float_as_uint(*pending));       // non-negative floats order as integers
+                                int* __restrict__ bad) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float m = *table_max;
+        if (*bad == 0 && *pending > m) { m = *pending; *table_max = m; }      // appends to a table run one at a time
+        bad[1] = (int)__float_as_uint(m);
+    }
 }
 
-hipError_t launch_fold_max(float* table_max, const float* pending, const int* bad, hipStream_t st) {
+hipError_t launch_fold_max(float* table_max, const float* pending, int* bad, hipStream_t st) {
     hipLaunchKernelGGL(fold_max_kernel, dim3(1), dim3(64), 0, st, table_max, pending, bad);
+    return hipGetLastError();
+}
+
+__device__ __forceinline__ bool norm_sampled(long long r) { return r < 4096 || (r & 63) == 0; }
+
+__global__ void __launch_bounds__(256)
+norm_hist_kernel(const float* __restrict__ n2, long long row0, long long n, unsigned int* __restrict__ hist) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = row0 + i;
+        if (!norm_sampled(r)) continue;
+        const float v = n2[r];
+        if (v > 0.f) atomicAdd(&hist[(__float_as_uint(v) >> 23) & 255u], 1u);     // zero rows say nothing about the scale
+    }
+}
+
+hipError_t launch_norm_hist(const float* n2, long long row0, long long n, unsigned int* hist256, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(norm_hist_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n2, row0, n, hist256);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256)
+collect_outliers_kernel(const float* __restrict__ n2, long long row0, long long n, float limit,
+                        long long* __restrict__ list, int* __restrict__ n_out, float* __restrict__ max_rest) {
+    float mx = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = row0 + i;
+        const float v = n2[r];
+        if (v > limit) {
+            const int pos = atomicAdd(n_out, 1);
+            if (pos < OUTLIER_CAP) list[pos] = r;
+        } else {
+            mx = fmaxf(mx, v);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax((unsigned int*)max_rest, __float_as_uint(mx));
+}
+
+hipError_t launch_collect_outliers(const float* n2, long long row0, long long n, float limit, long long* list,
+                                   int* n_out, float* max_rest, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(collect_outliers_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n2, row0, n, limit, list, n_out, max_rest);
     return hipGetLastError();
 }
 

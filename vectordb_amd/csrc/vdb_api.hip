@@ -92,6 +92,15 @@ struct Table {
     int*       h_bad = nullptr;          // pinned, device-visible: set by an append that met a non-finite row
     int*       d_bad = nullptr;          // device address of h_bad
     bool       vmm = false;
+    // IP tables: norm statistics and the list of rows far longer than the rest (table_stats_update).
+    // Updated under ins_mu before new rows are published; searches copy `pub` under stat_mu.
+    char*         d_stat = nullptr;      // hist[256] u32 | n_out int | max_rest float | pad | two lists of OUTLIER_CAP rows
+    int64_t       stat_rows = 0;         // rows the histogram and the list cover
+    float         cand_limit = __builtin_huge_valf();     // 64 x the upper edge of the median bucket of n2
+    float         limit_used = __builtin_huge_valf();     // limit the current list was built with (inf: no list)
+    int           out_cur = 0;           // which of the two lists is current
+    std::mutex    stat_mu;
+    struct OutPub { float limit = __builtin_huge_valf(); const long long* list = nullptr; int n = 0; float max_rest = 0.f; } pub;
     std::shared_mutex mu;                // shared: searches and appends; exclusive: drop (and growth without VMM)
     std::mutex ins_mu;                   // appends to this table run one at a time
     bool dropped = false;
@@ -147,7 +156,8 @@ struct Global {
     // merging of concurrent blocking host searches (see vdb_search and host_merge.h)
     int coalesce_host = 1;
     std::atomic<int> debug_fail_map{0};  // test hook, see varray_map
-    long long mirrors_dropped = 0;       // tables whose bf16 mirror made room for rows (table_drop_mirror)
+    long long mirrors_dropped = 0;
+    int ip_outliers = 1;                 // IP tables keep rows far longer than the rest on a side list (table_stats_update)       // tables whose bf16 mirror made room for rows (table_drop_mirror)
 };
 static Global G;
 
@@ -523,7 +533,7 @@ static int search_gemm_path(const TableView& tv_in, const SelGeom& g, int dpad, 
         VDB_HIP(hipMemsetAsync(lost, 0, (size_t)nqc * 4, st));
         VDB_HIP(hipMemsetD32Async((hipDeviceptr_t)thr1, (int)0xff800000, (size_t)nqc, st));      // -inf
         VDB_HIP(gemm(tv0, thr1, 1, (n0 + 127) / 128, 1));
-        VDB_HIP(launch_kth_threshold(cs, GEMM_CAP, cnt, 0, GEMM_CAP, K, nullptr, thr0, nqi, st));
+        VDB_HIP(launch_kth_threshold(cs, GEMM_CAP, cnt, 0, GEMM_CAP, K, nullptr, thr0, nqi, st, &tv, nullptr));   // slot = row
         float* tau = thr0;
         float* spare = thr1;
         for (long long tiles : level_tiles) {
@@ -533,7 +543,7 @@ static int search_gemm_path(const TableView& tv_in, const SelGeom& g, int dpad, 
             if (pp) VDB_HIP(launch_gemm_pp(tv, qimg, nqi, dpad, tau, stride, 0, -1, cs, ct, cnt, lost, GEMM_CAP, G.n_cu, st));
             else if (s32) VDB_HIP(launch_gemm32s(use_m ? tvm : tv, qhi, qlo, qstride, s32split, nqi, use_m ? (int)tv.ld16 : dpad, tau, stride, cs, ct, cnt, lost, GEMM_CAP, G.n_cu, st));
             else VDB_HIP(gemm(tv, tau, stride, ntiles / stride, 0));
-            VDB_HIP(launch_kth_threshold(cs, GEMM_CAP, cnt, 0, GEMM_CAP, K, tau, spare, nqi, st));
+            VDB_HIP(launch_kth_threshold(cs, GEMM_CAP, cnt, 0, GEMM_CAP, K, tau, spare, nqi, st, &tv, ct));
             std::swap(tau, spare);
         }
         // last pass: all row tiles
@@ -551,7 +561,7 @@ static int search_gemm_path(const TableView& tv_in, const SelGeom& g, int dpad, 
             const long long part = G.tune_pp_parts ? tpp / 8 : 0;
             if (part >= 4LL * G.n_cu) {
                 VDB_HIP(launch_gemm_pp(tv, qimg, nqi, dpad, tau, 1, 0, part, cs, ct, cnt, lost, GEMM_CAP, G.n_cu, st));
-                VDB_HIP(launch_kth_threshold(cs, GEMM_CAP, cnt, 0, GEMM_CAP, K, tau, spare, nqi, st));
+                VDB_HIP(launch_kth_threshold(cs, GEMM_CAP, cnt, 0, GEMM_CAP, K, tau, spare, nqi, st, &tv, ct));
                 std::swap(tau, spare);
                 VDB_HIP(launch_gemm_pp(tv, qimg, nqi, dpad, tau, 1, part, -1, cs, ct, cnt, lost, GEMM_CAP, G.n_cu, st));
             } else {
@@ -577,6 +587,12 @@ static int search_core(Table& t, int64_t nq, const float* q_dev, int k, long lon
     tv.rows = t.d_rows; tv.ids = t.d_ids; tv.n2 = t.d_n2; tv.max_n2 = t.d_maxn2;
     tv.rows16 = t.d_rows16; tv.ld16 = t.ld16;
     tv.n = t.rows.load(std::memory_order_acquire); tv.d = (int)t.dim; tv.m = t.m; tv.dt = t.dtype; tv.metric = t.metric;
+    {
+        // the list covers every row this search sees (it is brought up to date before rows are published); entries
+        // of rows past tv.n are skipped by the kernels
+        std::lock_guard<std::mutex> lk(t.stat_mu);
+        if (t.pub.n > 0) { tv.out_limit = t.pub.limit; tv.outliers = t.pub.list; tv.n_out = t.pub.n; tv.max_rest = t.pub.max_rest; }
+    }
     const int l2 = t.metric == VDB_METRIC_L2;
     if (tv.n == 0) {
         const long long tot = nq * k > nq ? nq * k : nq;
@@ -822,6 +838,12 @@ static void table_free(Table& t) {
     size_t have = 0;
     for (VArray* a : {&t.a_rows, &t.a_ids, &t.a_n2, &t.a_rows16}) { have += a->mapped; varray_free(*a); }
     if (t.d_maxn2) (void)hipFree(t.d_maxn2);
+    if (t.d_stat) (void)hipFree(t.d_stat);
+    t.d_stat = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(t.stat_mu);
+        t.pub = Table::OutPub();
+    }
     if (t.h_bad) (void)hipHostFree(t.h_bad);
     t.d_rows = nullptr; t.d_ids = nullptr; t.d_n2 = nullptr; t.d_rows16 = nullptr; t.d_maxn2 = nullptr;
     t.h_bad = nullptr; t.d_bad = nullptr;
@@ -971,6 +993,7 @@ int vdb_set_option(const char* key, double value) {
     else if (k == "l2_row_bounds") G.row_bounds = value != 0;
     else if (k == "bf16_mirror") G.bf16_mirror = value != 0;
     else if (k == "virtual_ranges") G.use_vmm = value != 0;
+    else if (k == "ip_outliers") G.ip_outliers = value != 0;
     else if (k == "debug_fail_map") G.debug_fail_map.store(value > 0 ? (int)value : 0);
     else return fail(VDB_EINVAL, "unknown option: " + k);
     set_scan_tune(G.tune_nt, G.tune_waves, G.tune_bpc, G.tune_contig, G.tune_dyn);
@@ -1000,8 +1023,8 @@ int vdb_create_table(const char* name, int64_t dim, int metric, int dtype) {
     else t->ld16 = (int64_t)t->m * 8;
     VDB_HIP(hipMalloc((void**)&t->d_maxn2, 16));
     VDB_HIP(hipMemset(t->d_maxn2, 0, 16));
-    hipError_t e = hipHostMalloc((void**)&t->h_bad, sizeof(int), hipHostMallocMapped);
-    if (e == hipSuccess) { *t->h_bad = 0; e = hipHostGetDevicePointer((void**)&t->d_bad, t->h_bad, 0); }
+    hipError_t e = hipHostMalloc((void**)&t->h_bad, 4 * sizeof(int), hipHostMallocMapped);       // [0] refused row seen, [1] bits of the norm bound
+    if (e == hipSuccess) { t->h_bad[0] = 0; t->h_bad[1] = 0; e = hipHostGetDevicePointer((void**)&t->d_bad, t->h_bad, 0); }
     if (e != hipSuccess) {
         (void)hipFree(t->d_maxn2);
         if (t->h_bad) (void)hipHostFree(t->h_bad);
@@ -1112,6 +1135,72 @@ int vdb_reserve(const char* name, int64_t rows) {
     return rc;
 }
 
+// IP on raw vectors is the reference's metric (/root/reference/app.py:22,141), and the bounds of the
+// batched path scale with the longest row of the table: a few rows a hundred times longer than the rest
+// (and unrelated to the queries) would send every batched query to the exact pass.  Such rows are kept on a
+// list instead: rows whose squared norm exceeds 64 x the upper edge of the median bucket of a histogram
+// of the norms' exponents (8 to 11 times the typical norm).  The batched path takes its bound over the
+// other rows and re-scores the listed ones canonically for every query (finalize_band_kernel).  More
+// than OUTLIER_CAP such rows: no list, the table-wide bound as before.  Called with ins_mu held, after
+// rows [stat_rows, end) have landed and before they are published.
+static int table_stats_update(Table& t, int64_t end, hipStream_t st) {
+    if (t.metric != VDB_METRIC_IP || !G.ip_outliers || end <= t.stat_rows) { t.stat_rows = end > t.stat_rows ? end : t.stat_rows; return VDB_OK; }
+    const float inf = __builtin_huge_valf();
+    if (!t.d_stat) {
+        VDB_HIP(hipMalloc((void**)&t.d_stat, 2048 + 2 * OUTLIER_CAP * sizeof(long long)));
+        VDB_HIP(hipMemsetAsync(t.d_stat, 0, 2048, st));
+    }
+    unsigned int* d_hist = (unsigned int*)t.d_stat;
+    int* d_nout = (int*)(t.d_stat + 1024);
+    float* d_maxrest = (float*)(t.d_stat + 1028);
+    long long* lists[2] = {(long long*)(t.d_stat + 2048), (long long*)(t.d_stat + 2048) + OUTLIER_CAP};
+    const int64_t row0 = t.stat_rows, n = end - row0;
+    const bool sampled = row0 < 4096 || ((row0 + 63) & ~(int64_t)63) < end;
+    if (sampled) {
+        unsigned int h[256];
+        VDB_HIP(launch_norm_hist(t.d_n2, row0, n, d_hist, st));
+        VDB_HIP(hipMemcpyAsync(h, d_hist, sizeof h, hipMemcpyDeviceToHost, st));
+        VDB_HIP(hipStreamSynchronize(st));
+        unsigned long long total = 0, acc = 0;
+        for (unsigned v : h) total += v;
+        t.cand_limit = inf;
+        if (total >= 16) {
+            int b = 0;
+            for (; b < 256; ++b) { acc += h[b]; if (2 * acc >= total) break; }
+            if (b >= 1 && b <= 240) t.cand_limit = std::ldexp(64.0f, b - 126);        // bucket b holds [2^(b-127), 2^(b-126))
+        }
+    }
+    const float maxn2 = __builtin_bit_cast(float, t.h_bad[1]);
+    const bool want = maxn2 > t.cand_limit;
+    Table::OutPub pub;
+    if (want) {
+        const bool extend = t.limit_used == t.cand_limit;
+        if (!extend) {
+            // another limit: the list is built anew in the buffer no search reads (searches enqueued long
+            // ago may still read the one before: wait for them)
+            VDB_HIP(hipDeviceSynchronize());
+            t.out_cur ^= 1;
+            VDB_HIP(hipMemsetAsync(d_nout, 0, 8, st));
+            VDB_HIP(launch_collect_outliers(t.d_n2, 0, end, t.cand_limit, lists[t.out_cur], d_nout, d_maxrest, st));
+            t.limit_used = t.cand_limit;
+        } else {
+            VDB_HIP(launch_collect_outliers(t.d_n2, row0, n, t.limit_used, lists[t.out_cur], d_nout, d_maxrest, st));
+        }
+        struct { int n; float mr; } res;
+        VDB_HIP(hipMemcpyAsync(&res, d_nout, sizeof res, hipMemcpyDeviceToHost, st));
+        VDB_HIP(hipStreamSynchronize(st));
+        if (res.n > 0 && res.n <= OUTLIER_CAP) { pub.limit = t.limit_used; pub.list = lists[t.out_cur]; pub.n = res.n; pub.max_rest = res.mr; }
+    } else {
+        t.limit_used = inf;
+    }
+    {
+        std::lock_guard<std::mutex> lk(t.stat_mu);
+        t.pub = pub;
+    }
+    t.stat_rows = end;
+    return VDB_OK;
+}
+
 // Appends run one at a time per table and beside searches: the new rows are written behind the
 // published row count, the stream is drained, and only then is the count advanced (one atomic
 // store), so a search sees either none or all rows of a call.  A call that meets a row that is not
@@ -1157,6 +1246,7 @@ static int insert_locked(Table& t, int64_t n, const float* rows, const long long
         }
     }
     if (*t.h_bad) return fail(VDB_EINVAL, "a row holds a value that is not finite in the table's storage type; nothing was inserted");
+    if ((rc = table_stats_update(t, base + n, (synth || host) ? G.insert_stream : user_st))) return rc;
     t.rows.store(base + n, std::memory_order_release);
     return VDB_OK;
 }
@@ -1545,6 +1635,10 @@ int vdb_load_table(const char* name, const char* path) {
         }
         if (!rc && hipMemcpy(t->d_maxn2, &h.max_n2, sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
             rc = fail(VDB_EHIP, "cannot store the row-norm bound");
+        if (!rc) {
+            t->h_bad[1] = (int)__builtin_bit_cast(unsigned int, h.max_n2);
+            rc = table_stats_update(*t, h.rows, nullptr);
+        }
         if (!rc) t->rows.store(h.rows);
     }
     if (rc) {

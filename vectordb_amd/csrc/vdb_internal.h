@@ -39,7 +39,23 @@ struct TableView {
     int              dt;        // VDB_F32 / VDB_BF16 / VDB_F16
     int              metric;    // VDB_METRIC_*
     RowBound         rb;        // L2 searches: per-row error term of this call's passes
+    // IP tables with a few rows far longer than the rest (see OutlierView): the batched path's bounds are
+    // taken over the other rows, and every query re-scores the long ones canonically
+    float            out_limit = __builtin_huge_valf();   // rows with n2 above this are on the list (inf: no list)
+    const long long* outliers = nullptr;                  // their row indices, ascending by arrival
+    int              n_out = 0;
+    float            max_rest = 0.f;                       // largest n2 among the rows not on the list
 };
+
+// Norm statistics of an IP table (kernels_store.hip): a histogram of the exponents of the rows' squared
+// norms over a sample of the rows (every row below 4096, every 64th beyond) gives the typical norm;
+// rows whose squared norm exceeds `limit` are collected on a list, up to OUTLIER_CAP of them.
+constexpr int OUTLIER_CAP = 1024;
+hipError_t launch_norm_hist(const float* n2, long long row0, long long n, unsigned int* hist256, hipStream_t st);
+// appends the rows of [row0, row0 + n) with n2 > limit to list (count in *n_out, entries past OUTLIER_CAP
+// are dropped but counted) and raises *max_rest to the largest n2 <= limit among them
+hipError_t launch_collect_outliers(const float* n2, long long row0, long long n, float limit, long long* list,
+                                   int* n_out, float* max_rest, hipStream_t st);
 
 #if defined(__HIPCC__)
 // (brel bq + cabs) for the launch; every wave evaluates it by itself
@@ -159,8 +175,11 @@ hipError_t launch_split_query16(int dt, const float* qprep, int nq, int dpad, in
                                 unsigned short* lo, int* bad, hipStream_t st);
 // thr_out[q] = max(thr_in[q], K-th best key among query q's candidates); candidates of query q start
 // at cand_s + q*stride and number cnt[q] (capped at cap), or count_all when cnt is null.
+// With `t` given, candidates whose row is on the table's list of long rows (n2 above t->out_limit) do not
+// count: their fast keys say little.  cand_t null: slot i holds row i.
 hipError_t launch_kth_threshold(const float* cand_s, long long stride, const int* cnt, long long count_all,
-                                int cap, int K, const float* thr_in, float* thr_out, int nq, hipStream_t st);
+                                int cap, int K, const float* thr_in, float* thr_out, int nq, hipStream_t st,
+                                const TableView* t = nullptr, const long long* cand_t = nullptr);
 
 // Exact second pass for the queries whose fast pass could not be certified.
 hipError_t launch_exact(const TableView& t, const float* qprep, int64_t nq, int dpad,
@@ -175,8 +194,8 @@ hipError_t launch_append(char* rows, unsigned short* rows16, long long ld16, lon
                          const float* raw, const long long* raw_ids,
                          uint64_t seed, long long synth_first_row, hipStream_t st);
 
-// table_max = max(table_max, *pending) unless *bad is set (see fold_max_kernel)
-hipError_t launch_fold_max(float* table_max, const float* pending, const int* bad, hipStream_t st);
+// table_max = max(table_max, *pending) unless *bad is set; bad[1] = bits of table_max afterwards (see fold_max_kernel)
+hipError_t launch_fold_max(float* table_max, const float* pending, int* bad, hipStream_t st);
 
 // (re)builds the bf16 mirror of rows [row0, row0 + n) of an fp32 table from the stored rows
 hipError_t launch_build_mirror(const char* rows, unsigned short* rows16, long long ld16, long long row0,
