@@ -368,16 +368,21 @@ def rank_main(args, world: int) -> None:
                 pp = nq_launch > 128 and products == 1 and opts.get("gemm_pp") != "0" and opts.get("bf16_mirror") != "0"
                 peak = MFMA_16_PEAK_TF / products
                 entry["roofline"] = {
-                    "bound": "mfma", "kernel": "gemm_pp_kernel" if pp else "gemm32s_kernel", "achieved": tf, "peak": peak,
+                    "bound": "mfma", "kernel": ("gemm_pp384_kernel" if (opts.get("gemm_pp_tile") == "384" or (nq_launch <= 256 and opts.get("gemm_pp_tile") != "256"))
+                                                        else "gemm_pp_kernel") if pp else "gemm32s_kernel",
+                    "achieved": tf, "peak": peak,
                     "unit": "TFLOP/s", "frac": tf / peak, "traffic": None,
                     "flops_per_launch": flops, "mfma_flops_per_launch": products * flops,
                     "avg_launch_ms": avg_s * 1e3, "launches_timed": launches,
                     "row_bytes_per_launch": bytes_per_launch, "row_read_gbs_if_read_once": gbs,
                 }
+                # small batches sit near the ridge: the same launch against the HBM peak (rows read once per pass)
+                entry["roofline"]["hbm_frac_if_rows_read_once"] = gbs / HBM_PEAK_GBS
                 if dtype == "f32" and products == 1 and opts.get("bf16_mirror") != "0":
                     # these passes read the bf16 mirror of the fp32 rows
                     entry["roofline"]["row_bytes_per_launch"] = mirror_bytes
                     entry["roofline"]["row_read_gbs_if_read_once"] = mirror_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
+                    entry["roofline"]["hbm_frac_if_rows_read_once"] = entry["roofline"]["row_read_gbs_if_read_once"] / HBM_PEAK_GBS
                 if nq < 128:
                     # less than one 128-query tile: the pass is bound by reading the rows once
                     rb = entry["roofline"]["row_bytes_per_launch"]
@@ -393,7 +398,7 @@ def rank_main(args, world: int) -> None:
                 tj = json.load(fh)
             key = "%s|rows_per_gpu=%d|dim=%d|dtype=%s|nq=%d" % (entry["roofline"]["kernel"], n_local, dim, dtype, min(nq, 1024))
             pmc = tj.get(key)
-            if pmc and not args.opt:
+            if pmc and not args.opt and pmc.get("hbm_read_bytes_per_launch"):
                 entry["roofline"]["traffic"] = pmc["hbm_read_bytes_per_launch"]
                 entry["roofline"]["traffic_source"] = pmc["source"]
         except (OSError, ValueError):

@@ -93,7 +93,8 @@ int vdb_shutdown(void);
  * 256 = 4 waves over 128 rows, two workgroups per CU).
  * "gemm_pp" (1 = batches of more than 128 queries run on the ping-pong kernel that loads its
  * operands straight into LDS (default); 0 = the converting kernel for every batch size),
- * "gemm_pp_tile" (rows per tile of that kernel: 384 = 384 x 256 tiles (default), 256 = 256 x 256 tiles),
+ * "gemm_pp_tile" (rows per tile of that kernel: 0 = 384 x 256 tiles for launches of up to 256 queries and
+ * 256 x 256 tiles beyond (default); 256 or 384 = that shape for every launch),
  * "gemm_pp_parts" (1 = the last pass of that kernel tightens its threshold after an eighth of the
  * rows (default)).
  * Store: "bf16_mirror" (1 = fp32 tables keep a bf16 copy of their rows, half of the table again in

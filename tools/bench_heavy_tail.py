@@ -104,7 +104,7 @@ def main():
             settings = [(r, 1) for r in args.row_bounds] if mname == "l2" else [(1, o) for o in args.ip_outliers]
             for rbnd, outl in settings:
                 eng.set_option("l2_row_bounds", rbnd)
-                if mname == "ip" and outl != 1:
+                if mname == "ip" and outl != 1 and len(args.ip_outliers) > 1:
                     # the list is built while rows arrive: a table filled without it
                     print("(ip_outliers=%d needs a refill; run the script with --ip-outliers %d alone)" % (outl, outl), flush=True)
                 single(5)

@@ -57,6 +57,17 @@ struct Workspace {
     DevBuf q_raw, o_ids, o_scores, o_counts;              // staging of the host entry point (o_ids holds ids | scores | counts)
     void*  h_pin = nullptr;                               // pinned host mirror: queries | ids | scores | counts
     size_t h_cap = 0;
+    // Blocking host calls: the lists of flagged queries live inside the block the caller copies back anyway
+    // (ne_ext), and the exact pass is launched by the caller only when the copied-back list holds a query
+    // (defer_exact): two early-exit launches less per call on the path whose cost is all fixed cost.
+    int*   ne_ext = nullptr;
+    bool   defer_exact = false;
+    struct Deferred {
+        bool pending = false;
+        TableView tv; const float* qprep = nullptr; int64_t nq = 0; int dpad = 0; SelGeom g{}; int Gxe = 0; int k = 0;
+        float* cs = nullptr; long long* ct = nullptr; long long* out_ids = nullptr; float* out_scores = nullptr;
+        int* out_counts = nullptr; int* flagged = nullptr;
+    } deferred;
 };
 
 // A device array that grows in place: a virtual address range is reserved once for the largest size
@@ -337,7 +348,7 @@ static int search_scan_path(const TableView& tv_in, const SelGeom& g, int dpad, 
     if ((rc = ensure(ws.cand_s, (size_t)nqc * lists * g.K * sizeof(float), ws.last_stream, ws.fixed))) return rc;
     if ((rc = ensure(ws.cand_t, (size_t)nqc * lists * g.K * sizeof(long long), ws.last_stream, ws.fixed))) return rc;
     if ((rc = ensure(ws.cand_h, (size_t)nqc * lists * sizeof(float), ws.last_stream, ws.fixed))) return rc;
-    if ((rc = ensure(ws.need_exact, (size_t)(2 * nqc + 2) * sizeof(int), ws.last_stream, ws.fixed))) return rc;
+    if (!ws.ne_ext && (rc = ensure(ws.need_exact, (size_t)(2 * nqc + 2) * sizeof(int), ws.last_stream, ws.fixed))) return rc;
     // Many short rows and a long candidate list: every wave would spend its first K*ln(rows/K)
     // rows filling and sorting its own list.  A scan of a small sample of the rows (1/256) first
     // gives the K-th best key of the sample, a lower bound of the K-th best key of the table; the
@@ -364,7 +375,7 @@ static int search_scan_path(const TableView& tv_in, const SelGeom& g, int dpad, 
         QInfo* qinfo = (QInfo*)ws.qinfo.p;
         float* cs = (float*)ws.cand_s.p;
         long long* ct = (long long*)ws.cand_t.p;
-        int* ne = (int*)ws.need_exact.p;
+        int* ne = ws.ne_ext ? ws.ne_ext : (int*)ws.need_exact.p;
         // L2 keys carry the error term of their own row (see RowBound)
         if (tv.metric == VDB_METRIC_L2 && G.row_bounds) tv.rb = tsc.rb = tvs.rb = l2_row_bound(fb, tv.d, qinfo, (int)nqi);
         VDB_HIP(launch_prep_query(q_dev + (size_t)q0 * tv.d, nqi, tv.d, dpad, tv.metric, qprep, qinfo, ne, st));
@@ -415,6 +426,12 @@ static int search_scan_path(const TableView& tv_in, const SelGeom& g, int dpad, 
                                     out_ids + (size_t)q0 * k, out_scores + (size_t)q0 * k, out_counts + q0,
                                     ne2, G.d_counters, fb2, ne, st));
             flagged = ne2;
+        }
+        if (ws.defer_exact && nq <= chunk) {
+            Workspace::Deferred& df = ws.deferred;
+            df.pending = true; df.tv = tv; df.qprep = qprep; df.nq = nqi; df.dpad = dpad; df.g = g; df.Gxe = Gxe; df.k = k;
+            df.cs = cs; df.ct = ct; df.out_ids = out_ids; df.out_scores = out_scores; df.out_counts = out_counts; df.flagged = flagged;
+            continue;
         }
         VDB_HIP(launch_exact(tv, qprep, nqi, dpad, g, Gxe, k, cs, ct,
                              out_ids + (size_t)q0 * k, out_scores + (size_t)q0 * k, out_counts + q0,
@@ -557,7 +574,7 @@ static int search_gemm_path(const TableView& tv_in, const SelGeom& g, int dpad, 
             // the other seven eighths (candidates per query at 10 M rows: 2000 -> 500).  Candidates of both
             // parts stay in the array; the finalize step is told the tighter threshold, which is valid
             // for every row that is not a candidate.
-            const long long tpp = (tv.n + pp_tile_rows() - 1) / pp_tile_rows();
+            const long long tpp = (tv.n + pp_tile_rows(nqi) - 1) / pp_tile_rows(nqi);
             const long long part = G.tune_pp_parts ? tpp / 8 : 0;
             if (part >= 4LL * G.n_cu) {
                 VDB_HIP(launch_gemm_pp(tv, qimg, nqi, dpad, tau, 1, 0, part, cs, ct, cnt, lost, GEMM_CAP, G.n_cu, st));
@@ -1771,7 +1788,10 @@ static void search_host_batch(std::vector<HostReq*>& batch) {
     // one by one and cost several times the 3 KB they move.
     const size_t qbytes = (size_t)nq * d * sizeof(float);
     const size_t ib = (size_t)nq * k * sizeof(long long), sb = (size_t)nq * k * sizeof(float), cb = (size_t)nq * sizeof(int);
-    const size_t obytes = ib + sb + cb;
+    const size_t rbytes = ib + sb + cb;                      // the results
+    // up to 256 queries (one chunk of the scan path): the lists of flagged queries ride behind the results
+    const size_t nbytes = nq <= 256 ? round_up((size_t)(2 * nq + 2) * sizeof(int), 16) : 0;
+    const size_t obytes = round_up(rbytes, 16) + nbytes;
     const bool pinned = qbytes + obytes <= ((size_t)64 << 20);
     do {
         if ((rc = ensure(ws->q_raw, qbytes, ws->last_stream))) break;
@@ -1801,10 +1821,28 @@ static void search_host_batch(std::vector<HostReq*>& batch) {
         if (e != hipSuccess) { rc = fail(VDB_EHIP, std::string("query upload: ") + hipGetErrorString(e)); break; }
         {
             std::shared_lock<std::shared_mutex> tl(tab.mu);
+            const bool defer = pinned && nbytes > 0;
+            ws->ne_ext = defer ? (int*)(o_dev + round_up(rbytes, 16)) : nullptr;
+            ws->defer_exact = defer;
+            ws->deferred.pending = false;
             if (tab.dropped) rc = fail(VDB_ENOTFOUND, "table was dropped");
             else rc = search_core(tab, nq, (const float*)ws->q_raw.p, k, (long long*)o_dev,
                                   (float*)(o_dev + ib), (int*)(o_dev + ib + sb), st, *ws);
-            if (rc == VDB_OK) {
+            ws->defer_exact = false;
+            if (rc == VDB_OK && defer && ws->deferred.pending) {
+                // results and the list of flagged queries in one copy; the exact pass only if the list holds a query
+                e = hipMemcpyAsync(ho, o_dev, obytes, hipMemcpyDeviceToHost, st);
+                if (e == hipSuccess) e = hipStreamSynchronize(st);
+                const Workspace::Deferred& df = ws->deferred;
+                const int* hne = (const int*)(ho + round_up(rbytes, 16)) + (df.flagged - ws->ne_ext);
+                if (e == hipSuccess && hne[0] > 0) {
+                    e = launch_exact(df.tv, df.qprep, df.nq, df.dpad, df.g, df.Gxe, df.k, df.cs, df.ct, df.out_ids, df.out_scores,
+                                     df.out_counts, df.flagged, G.d_counters, st);
+                    if (e == hipSuccess) e = hipMemcpyAsync(ho, o_dev, rbytes, hipMemcpyDeviceToHost, st);
+                    if (e == hipSuccess) e = hipStreamSynchronize(st);
+                }
+                if (e != hipSuccess) rc = fail(VDB_EHIP, std::string("result download: ") + hipGetErrorString(e));
+            } else if (rc == VDB_OK) {
                 if (pinned) {
                     e = hipMemcpyAsync(ho, o_dev, obytes, hipMemcpyDeviceToHost, st);
                 } else {
@@ -1832,6 +1870,7 @@ static void search_host_batch(std::vector<HostReq*>& batch) {
             }
         }
     } while (0);
+    ws->ne_ext = nullptr; ws->defer_exact = false; ws->deferred.pending = false;
     release_ws(ws, st);
     for (HostReq* r : batch) { r->rc = rc; if (rc != VDB_OK) r->err = tl_error; }
 }

@@ -153,12 +153,12 @@ hipError_t launch_gemm16_thresh(const TableView& t, const unsigned short* qhi, c
                                 float* cand_s, long long* cand_t, int* cnt, int* lost, int cap, int dense,
                                 int n_cu, hipStream_t st);
 void set_gemm32s_threads(int v);
-// Ping-pong kernels (gemm_pp384.h: 384 x 256 tiles, the default; gemm_pp.h: 256 x 256) over t.rows16
-// with the queries as a tiled 16-bit image (launch_tile_query16); visits every tile_stride-th tile of
-// pp_tile_rows() rows, tile0 and tile_count in units of visited tiles.  Needs nks * 32 <= t.ld16 or,
-// for 16-bit tables, dpad a multiple of 32 (pp_eligible).
+// Ping-pong kernels (gemm_pp384.h: 384 x 256 tiles, for launches of up to 256 queries; gemm_pp.h: 256 x 256)
+// over t.rows16 with the queries as a tiled 16-bit image (launch_tile_query16); visits every tile_stride-th
+// tile of pp_tile_rows(nq) rows, tile0 and tile_count in units of visited tiles.  Needs nks * 32 <= t.ld16
+// or, for 16-bit tables, dpad a multiple of 32 (pp_eligible).
 void set_pp_tile_rows(int v);
-int pp_tile_rows();
+int pp_tile_rows(int nq);
 bool pp_eligible(const TableView& t, int dpad);
 size_t pp_query_image_bytes(int nq, int dpad);
 hipError_t launch_tile_query16(int dt, int l2, const float* qprep, int nq, int dpad, unsigned short* image,
