@@ -251,6 +251,25 @@ def rank_main(args, world: int) -> None:
         last_ids = out.ids.cpu().numpy().copy()
         last_scores = out.scores.cpu().numpy().copy()
 
+        # When is a query's answer complete while queries are pipelined over several streams?  Outside the timed
+        # region, with the same issue pattern: a pair of events around every step on its stream (the first fires
+        # when the stream is free for the step, i.e. when the step two or three before it has completed).
+        pipe_lat = None
+        if nq == 1 and n_streams > 1 and latency:
+            nlat = min(steps, 60)
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nlat)]
+            for j in range(nlat):
+                i = warmup + (j % steps)
+                with torch.cuda.stream(streams[i % n_streams]):
+                    evs[j][0].record()
+                step(i)
+                with torch.cuda.stream(streams[i % n_streams]):
+                    evs[j][1].record()
+            fence()
+            ms = np.sort(np.array([a.elapsed_time(b) for a, b in evs[n_streams:]]))
+            pipe_lat = {"p50": float(np.percentile(ms, 50)), "p99": float(np.percentile(ms, 99)), "steps": int(ms.size),
+                        "what": "first kernel of a query started on its stream -> its answer complete, %d streams in flight" % n_streams}
+
         # per-phase breakdown of a step, outside the timed region: what the host spends enqueueing each
         # phase while steps are pipelined, and how long each phase takes on the device when nothing overlaps
         trace = None
@@ -332,6 +351,7 @@ def rank_main(args, world: int) -> None:
                 "avg_launch_ms": avg_s * 1e3, "launches_timed": launches, "timed_every": timed_every,
             },
             "host_latency_ms": host_lat,
+            "pipelined_completion_ms": pipe_lat,
             "sample_result": {"ids": [int(x) for x in last_ids[0][:3]], "scores": [float(x) for x in last_scores[0][:3]]},
         }
         if trace is not None:
@@ -442,6 +462,21 @@ def rank_main(args, world: int) -> None:
             secondary.append(e)
             drop_and_settle(name, rows * dim * DTYPES[dtype][1])
 
+        # BASELINE's first configuration as the reference runs it: 10 000 x 384 U[0,1) vectors, one PUT /insert each,
+        # then single-vector PUT /lookup calls, through the HTTP routes in this process (JSON, md5 ids, SQLite and the
+        # engine call included); the engine part of a lookup is the blocking vdb_search measured by
+        # tools/small_table_latency.py
+        try:
+            import contextlib
+            from tools.bench_http import run as http_run
+            with contextlib.redirect_stdout(sys.stderr):            # the routes print like the reference's do
+                h = http_run(10_000, 384, 100)
+            secondary.append({"metric": "PUT /lookup per second, 10000x384 f32 cosine top-10 through the HTTP routes",
+                              "value": h["lookup_qps"], "unit": "QPS", "lookup_ms": h["lookup_ms"],
+                              "insert_rows_per_s": h["insert_rows_per_s"], "workload": h["workload"], "dtype": "f32",
+                              "note": "BASELINE configuration 1 (the reference's own workload shape) end to end; no roofline: a call is all fixed cost"})
+        except Exception as exc:        # the HTTP layer needs flask; the kernels' numbers do not depend on it
+            secondary.append({"metric": "HTTP routes, 10000x384", "value": None, "note": "not measured: %s: %s" % (type(exc).__name__, exc)})
         # the single-query shapes first, the matrix-unit ones after them: a batched pass leaves the chip at a
         # lower clock for a while, which costs a scan of half a millisecond several per cent
         other(1_000_000, 768, "f32", "cosine", 10, 1, 1000, 100, "1M x 768 fp32 single query")
@@ -494,6 +529,7 @@ def rank_main(args, world: int) -> None:
             },
             "roofline": main_e["roofline"],
             "host_latency_ms": main_e["host_latency_ms"],
+            "pipelined_completion_ms": main_e.get("pipelined_completion_ms"),
             "sample_result": main_e["sample_result"],
         }
         if "trace" in main_e:

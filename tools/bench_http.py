@@ -17,12 +17,11 @@ from server.app import create_app  # noqa: E402
 from server.metastore import MetaStore  # noqa: E402
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--rows", type=int, default=10_000)
-    ap.add_argument("--dim", type=int, default=384)
-    ap.add_argument("--queries", type=int, default=100)
-    args = ap.parse_args()
+def run(rows=10_000, dim=384, queries=100):
+    class A:
+        pass
+    args = A()
+    args.rows, args.dim, args.queries = rows, dim, queries
     http = create_app(store=MetaStore()).test_client()
     name = "bench_http"
     http.get("/deletedb?dbname=" + name)
@@ -44,12 +43,21 @@ def main():
         assert r.status_code == 200 and len(json.loads(r.get_data(as_text=True))) >= 10
     lat = np.sort(np.array(lat[2:]))
     http.get("/deletedb?dbname=" + name)
-    print(json.dumps({
+    return {
         "workload": "%d x %d U[0,1) rows, one PUT /insert each; %d PUT /lookup (cosine top-10)" % (args.rows, args.dim, args.queries),
         "insert_rows_per_s": args.rows / t_ins,
         "lookup_qps": 1e3 / float(lat.mean()),
         "lookup_ms": {"p50": float(np.percentile(lat, 50)), "p99": float(np.percentile(lat, 99))},
-    }))
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=10_000)
+    ap.add_argument("--dim", type=int, default=384)
+    ap.add_argument("--queries", type=int, default=100)
+    args = ap.parse_args()
+    print(json.dumps(run(args.rows, args.dim, args.queries)))
 
 
 if __name__ == "__main__":
