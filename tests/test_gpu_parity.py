@@ -1095,3 +1095,38 @@ def test_long_rows_that_are_the_best_hits_are_still_found(engine, table_name, tm
     ids2 = np.concatenate([ids, np.array([2 ** 40], dtype=np.int64)])
     _check(engine, table_name, stored2, ids2, q, 10, O.IP)
     assert engine.stats()[1] == before[1]
+
+
+@pytest.mark.parametrize("d", [7, 384, 1100])
+def test_calls_of_a_few_queries_work_on_the_pinned_block_directly(engine, table_name, d):
+    """Blocking calls of up to four queries skip both copies (the kernels read the queries from pinned host
+    memory, write the answers there, and the caller watches one word per query): same bits as the copying
+    path (option host_direct 0) and as the oracle, for query blocks whose length is not a multiple of 16 bytes,
+    queries longer than the 1024 elements the preparation keeps in registers, the exact pass asked for
+    through the words, and the scan over the mirror, which does not write them."""
+    n = 6_000
+    rows = cases.make_rows("synth", 91, n, d)
+    ids = cases.make_ids("hash", 91, n)
+    stored = _load(engine, table_name, rows, ids, O.COSINE, _lib.F32)
+    q = cases.make_queries("synth", 92, 5, d, rows)
+    try:
+        for nq in (1, 3, 4, 5):
+            got = {}
+            for direct in (1, 0):
+                engine.set_option("host_direct", direct)
+                got[direct] = engine.search(table_name, q[:nq], 10)
+            for a, b in zip(got[1], got[0]):
+                assert np.array_equal(np.asarray(a).view(np.uint8), np.asarray(b).view(np.uint8))
+        engine.set_option("host_direct", 1)
+        _check(engine, table_name, stored, ids, q[:2], 10, O.COSINE)
+        engine.set_option("force_exact", 1)
+        _, f0, _ = engine.stats()
+        _check(engine, table_name, stored, ids, q[:3], 10, O.COSINE)
+        assert engine.stats()[1] - f0 == 3
+        engine.set_option("force_exact", 0)
+        engine.set_option("scan_mirror", 1)
+        _check(engine, table_name, stored, ids, q[:2], 10, O.COSINE)
+    finally:
+        engine.set_option("host_direct", 1)
+        engine.set_option("force_exact", 0)
+        engine.set_option("scan_mirror", 0)

@@ -1,18 +1,27 @@
-import ctypes as C, sys, os
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
-import torch
+"""Stage times of finalize_kernel on a small table (diagnostic library built with -DVDB_FIN_STAMPS):
+  hipcc ... -DVDB_FIN_STAMPS -o vectordb_amd/libvdb_stamps.so; VDB_LIBRARY=vectordb_amd/libvdb_stamps.so python tools/fin_stamps.py"""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
 from vectordb_amd import _lib
 from vectordb_amd.engine import Engine
 eng = Engine(0)
-eng.create_table("t", 768, _lib.METRIC_COSINE, _lib.F32)
-eng.insert_synthetic("t", 10_000_000, 0, 0)
-st = torch.cuda.current_stream().cuda_stream
-q = torch.empty((16, 768), dtype=torch.float32, device="cuda"); eng.synth_fill_dev(q.data_ptr(), 16, 768, 1, 0, st)
-oi = torch.empty((1, 10), dtype=torch.int64, device="cuda"); os_ = torch.empty((1, 10), dtype=torch.float32, device="cuda"); oc = torch.empty((1,), dtype=torch.int32, device="cuda")
-buf = (C.c_longlong * 32)()
-for r in range(6):
-    eng.search_dev("t", 1, q[r].data_ptr(), 10, oi.data_ptr(), os_.data_ptr(), oc.data_ptr(), st)
-    torch.cuda.synchronize()
-    eng.lib.vdb_debug_read(buf)
-    s = [buf[8 + i] for i in range(6)]
-    print("S=%d  stage us:" % buf[20], ["%.1f" % ((s[i + 1] - s[i]) / 100.0) for i in range(5)], "total %.1f" % ((s[5] - s[0]) / 100.0))
+lib = ctypes.CDLL(_lib.LIB_PATH)
+lib.vdb_debug_read.argtypes = [ctypes.POINTER(ctypes.c_longlong)]
+for rows, dim, k in [(10_000, 384, 10), (100_000, 384, 10), (10_000_000 // 8, 768, 10)]:
+    name = "st_%d_%d" % (rows, dim)
+    eng.create_table(name, dim, _lib.METRIC_IP, _lib.F32)
+    eng.insert_synthetic(name, rows, seed=0, first_row=0)
+    q = np.random.default_rng(1).random((64, dim)).astype(np.float32)
+    acc = []
+    for i in range(64):
+        eng.search(name, q[i:i + 1], k)
+        buf = (ctypes.c_longlong * 32)()
+        assert lib.vdb_debug_read(buf) == 0
+        s = [buf[8 + j] for j in range(6)]
+        c = [buf[16 + j] for j in range(6)]
+        if i >= 8:
+            acc.append([(s[j + 1] - s[j]) * 10 for j in range(5)] + [(c[5] - c[0]) / max(1, (s[5] - s[0]) * 10)])
+    a = np.median(np.array(acc), axis=0)
+    print("%8d x %d: heads+bound %.0f ns  walk %.0f  select %.0f  re-score %.0f  sort+write+certify %.0f  (sum %.0f)  shader clock %.2f GHz" % (rows, dim, a[0], a[1], a[2], a[3], a[4], a[:5].sum(), a[5]), flush=True)
+    eng.drop_table(name)

@@ -166,7 +166,8 @@ __device__ __forceinline__ void canon_score_rows(const char* const* row, const f
         for (int u = 0; u < UL; ++u) {
             const int j = j0 + 64 * u;
             const int jc = j < d ? j : d - 1;
-            yv[u] = j < d ? q[jc] : 0.f;
+            const float y = q[jc];                         // unconditional, like the row loads: a guarded load becomes a branch and a wait
+            yv[u] = j < d ? y : 0.f;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 float x;
@@ -225,23 +226,42 @@ prep_query_kernel(const float* __restrict__ q_raw, int d, int dpad, int metric,
     if (blockIdx.x == 0 && lane == 0) { need_exact[0] = 0; need_exact[1 + gridDim.x] = 0; }
     const float* q = q_raw + (size_t)blockIdx.x * d;
     float* out = qprep + (size_t)blockIdx.x * dpad;
+    // Sixteen elements per lane are fetched per round trip and, for queries of up to 1024 elements, read only once:
+    // the raw query may lie in host memory, where every dependent load is a trip over the bus.  The sums are formed
+    // in the order of the plain loop (lane l: elements l, l + 64, ... in increasing order).
+    const bool once = d <= 1024;
+    float xv[16];
     double acc = 0.0;
-    for (int j = lane; j < d; j += 64) { const double x = (double)q[j]; acc = __dadd_rn(acc, __dmul_rn(x, x)); }
+    for (int j0 = lane; j0 < d; j0 += 1024) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int j = j0 + 64 * u; xv[u] = q[j < d ? j : d - 1]; }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            if (j0 + 64 * u < d) { const double x = (double)xv[u]; acc = __dadd_rn(acc, __dmul_rn(x, x)); }
+        }
+    }
     double n2 = wave_tree_sum(acc);
     n2 = __shfl(n2, 0);
-    if (metric == VDB_METRIC_COSINE) {
-        const double inv = (n2 == 0.0) ? 0.0 : 1.0 / sqrt(n2);
-        double acc2 = 0.0;
-        for (int j = lane; j < dpad; j += 64) {
-            float y = 0.f;
-            if (j < d) y = (float)__dmul_rn((double)q[j], inv);
-            out[j] = y;
-            acc2 = __dadd_rn(acc2, __dmul_rn((double)y, (double)y));
+    const bool cosine = metric == VDB_METRIC_COSINE;
+    const double inv = (n2 == 0.0) ? 0.0 : 1.0 / sqrt(n2);
+    double acc2 = 0.0;
+    for (int j0 = lane; j0 < dpad; j0 += 1024) {
+        if (!once) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { const int j = j0 + 64 * u; xv[u] = q[j < d ? j : d - 1]; }
         }
-        n2 = __shfl(wave_tree_sum(acc2), 0);
-    } else {
-        for (int j = lane; j < dpad; j += 64) out[j] = (j < d) ? q[j] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int j = j0 + 64 * u;
+            if (j < dpad) {
+                float y = 0.f;
+                if (j < d) y = cosine ? (float)__dmul_rn((double)xv[u], inv) : xv[u];
+                out[j] = y;
+                acc2 = __dadd_rn(acc2, __dmul_rn((double)y, (double)y));
+            }
+        }
     }
+    if (cosine) n2 = __shfl(wave_tree_sum(acc2), 0);
     if (lane == 0) {
         QInfo qi;
         qi.n2 = n2;
@@ -703,6 +723,7 @@ struct FinParams {
     float*           floor_out;  // lists mode, non-null: only write the K-th best fast key per query and return
     int              fin_cap;    // lists mode: survivors the kernel's LDS holds (FIN_CAP or FIN_CAP_LONG)
     int              pth;        // lists mode: which entry of every list the first bound is taken from (fin_pth; 0: the heads, per thread)
+    int*             host_flag = nullptr;   // lists mode, non-null: [query] set once the answer is written: 1 final, 2 the query goes on to the exact pass (plain store; may be host memory)
 };
 
 __device__ __forceinline__ int pow2_ceil_dev(int v) { int p = 1; while (p < v) p <<= 1; return p; }
@@ -718,15 +739,18 @@ __device__ __forceinline__ float fkey_inv(uint32_t k) {
 
 // One histogram increment per distinct bin per wave instead of one per lane: scores of the
 // candidates share their leading bits, so a plain per-lane LDS atomic would serialise 64-fold.
+// Bins that few lanes share are cheaper left to the LDS atomics themselves (one increment per lane, spread over the
+// banks): after four rounds of aggregation the lanes still waiting add their own.
 __device__ __forceinline__ void hist_add_aggregated(int* hist, bool active, int bin) {
     unsigned long long todo = __ballot(active);
-    while (todo) {
+    for (int round = 0; todo && round < 4; ++round) {
         const int leader = __ffsll((long long)todo) - 1;
         const int b = __shfl(bin, leader);
         const unsigned long long same = __ballot(active && bin == b) & todo;
         if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[b], __popcll(same));
         todo &= ~same;
     }
+    if ((todo >> (threadIdx.x & 63)) & 1ull) atomicAdd(&hist[bin], 1);
 }
 
 // Block-wide K-th largest of `count` fp32 values by an 8-bit MSD radix select (four histogram
@@ -839,9 +863,14 @@ finalize_kernel(FinParams p) {
     uint32_t thr = 0;
     int need = K;
     bool take_all;
+    // what the certificate at the very end needs from memory is asked for now
+    const float pre_max_n2 = p.floor_out ? 0.f : *p.t.max_n2;
+    QInfo pre_qinfo;
+    pre_qinfo.n2 = 0.0; pre_qinfo.bq = 0.f; pre_qinfo.pad = 0.f;
+    if (!p.floor_out) pre_qinfo = p.qinfo[qi];
     // diagnostic build only (-DVDB_FIN_STAMPS): stage boundaries of query 0 in 10 ns ticks
 #ifdef VDB_FIN_STAMPS
-#define STAMP(n) do { if (tid == 0 && qi == 0 && p.counters != nullptr) p.counters[8 + (n)] = (long long)wall_clock64(); } while (0)
+#define STAMP(n) do { if (tid == 0 && qi == 0 && p.counters != nullptr) { p.counters[8 + (n)] = (long long)wall_clock64(); p.counters[16 + (n)] = (long long)clock64(); } } while (0)
 #else
 #define STAMP(n) do { } while (0)
 #endif
@@ -991,17 +1020,32 @@ finalize_kernel(FinParams p) {
     const bool l2 = p.t.metric == VDB_METRIC_L2;
     const float* q = p.q + (size_t)qi * p.dpad;
     const size_t rowbytes = (size_t)p.t.m * 16;
-    for (int i = wave; i < KR; i += W) {
-        float key = neg_inf();
-        long long id = TAG_NONE;
-        if (i < nvalid) {
-            const long long r = ST[i];
-            const double sc = canon_score(p.t.rows + (size_t)r * rowbytes, q, p.t.d, p.t.dt, l2, lane);
-            const float f = (float)sc;
-            key = l2 ? -f : f;
-            id = p.t.ids[r];
+    // four rows per wave and round, their loads in flight together (slots past the selected rows read row 0 and
+    // are dropped)
+    for (int i0 = wave; i0 < KR; i0 += 4 * W) {
+        const char* rp[4];
+        long long id[4];
+        double sc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = i0 + j * W;
+            const long long r = i < nvalid ? ST[i] : 0ll;
+            rp[j] = p.t.rows + (size_t)r * rowbytes;
+            id[j] = p.t.ids[r];
         }
-        if (lane == 0) { RS[i] = key; RT[i] = id; }
+#if defined(VDB_FIN_EXP) && VDB_FIN_EXP == 1
+        for (int j = 0; j < 4; ++j) sc[j] = (double)j;
+#else
+        if (i0 < nvalid) canon_score_rows_dt<4>(rp, q, p.t.d, p.t.dt, l2, lane, sc);      // wave-uniform
+#endif
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = i0 + j * W;
+            float key = neg_inf();
+            long long tag = TAG_NONE;
+            if (i < nvalid) { const float f = (float)sc[j]; key = l2 ? -f : f; tag = id[j]; }
+            if (lane == 0 && i < KR) { RS[i] = key; RT[i] = tag; }
+        }
     }
     __syncthreads();
     STAMP(4);
@@ -1040,8 +1084,8 @@ finalize_kernel(FinParams p) {
                 // theta: no row outside the candidate set has a larger fast key
                 double theta = (double)fkey_inv(prefix);
                 if (take_all) { float mn = SS[0]; for (int i = 1; i < nvalid; ++i) mn = fminf(mn, SS[i]); theta = (double)mn; }
-                const double bx = sqrt((double)(*p.t.max_n2)) * (1.0 + 1e-6);
-                const double bq = (double)p.qinfo[qi].bq;
+                const double bx = sqrt((double)pre_max_n2) * (1.0 + 1e-6);
+                const double bq = (double)pre_qinfo.bq;
                 const double u = 5.9604644775390625e-08;   // 2^-24
                 const double dd = (double)p.t.d * p.dd_mult + 16.0;
                 const double xq = p.extra_rel * bx * bq + p.extra_abs * bx;     // query rounding of the batched path
@@ -1050,16 +1094,21 @@ finalize_kernel(FinParams p) {
                     cert = (double)RS[cnt - 1] > theta + eps;
                 } else {
                     // keys that carry their own row's error term bound the canonical keys by themselves
-                    const double eps = (p.t.rb.qinfo ? 4.0 * u * p.qinfo[qi].n2
+                    const double eps = (p.t.rb.qinfo ? 4.0 * u * pre_qinfo.n2
                                                      : 1.05 * u * (2.0 * dd * bx * bq + 4.0 * (bx * bx + 2.0 * bx * bq)) + 2.0 * xq)
                                        + 4.0 * u * fabs(theta) + 1e-37;
                     const double dist_k = -(double)RS[cnt - 1];
-                    const double bound = p.qinfo[qi].n2 - theta - eps;     // outside rows are farther than this
+                    const double bound = pre_qinfo.n2 - theta - eps;     // outside rows are farther than this
                     cert = dist_k * (1.0 + 8.0 * u) + 1e-37 < bound;
                 }
             }
             if (p.force_exact) cert = false;
             if (!cert) { const int pos = atomicAdd(&p.need_exact[0], 1); p.need_exact[1 + pos] = qi; }
+            if (p.host_flag) {
+                // the answer above is out before the word that announces it
+                __threadfence_system();
+                *(volatile int*)&p.host_flag[qi] = cert ? 1 : 2;
+            }
             STAMP(5);
             if (!p.only) atomicAdd((unsigned long long*)&p.counters[0], 1ull);      // a second tier answers queries already counted
         }
@@ -1267,11 +1316,12 @@ hipError_t launch_finalize(const TableView& t, const float* qprep, const QInfo* 
                            int dpad, const SelGeom& g, int G, int k,
                            const float* cand_s, const long long* cand_t, const float* cand_h,
                            long long* out_ids, float* out_scores, int* out_counts,
-                           int* need_exact, long long* counters, const FlatBound& fb, const int* only, hipStream_t st) {
+                           int* need_exact, long long* counters, const FlatBound& fb, const int* only, hipStream_t st,
+                           int* host_flag) {
     FinParams p;
     p.t = t; p.q = qprep; p.qinfo = qinfo; p.dpad = dpad;
     p.K = g.K; p.C = g.C; p.G = G; p.k = k;
-    p.only = only;
+    p.only = only; p.host_flag = host_flag;
     p.cand_s = cand_s; p.cand_t = cand_t; p.cand_h = cand_h;
     p.out_ids = out_ids; p.out_scores = out_scores; p.out_counts = out_counts;
     p.need_exact = need_exact; p.counters = counters;

@@ -56,7 +56,13 @@ struct Workspace {
     DevBuf qimg;                                          // batched path: tiled 16-bit image of the queries (ping-pong kernel)
     DevBuf q_raw, o_ids, o_scores, o_counts;              // staging of the host entry point (o_ids holds ids | scores | counts)
     void*  h_pin = nullptr;                               // pinned host mirror: queries | ids | scores | counts
+    char*  d_pin = nullptr;                               // the same memory as the device sees it
     size_t h_cap = 0;
+    // Calls of a few queries skip both copies: the kernels read the queries from the pinned host block and write
+    // the answers into it (3 KB and 124 bytes over the bus instead of two copy operations in the stream), and the
+    // finalize step leaves one word per query there that says whether the query still needs the exact pass.
+    int*   host_flag = nullptr;
+    bool   host_flag_used = false;       // the search wrote the words (a search over the mirror, with its second tier, does not)
     // Blocking host calls: the lists of flagged queries live inside the block the caller copies back anyway
     // (ne_ext), and the exact pass is launched by the caller only when the copied-back list holds a query
     // (defer_exact): two early-exit launches less per call on the path whose cost is all fixed cost.
@@ -166,6 +172,7 @@ struct Global {
     hipStream_t chain_last = nullptr;
     // merging of concurrent blocking host searches (see vdb_search and host_merge.h)
     int coalesce_host = 1;
+    int host_direct = 1;                 // blocking calls of up to four queries read and write the pinned host block directly
     std::atomic<int> debug_fail_map{0};  // test hook, see varray_map
     long long mirrors_dropped = 0;
     int ip_outliers = 1;                 // IP tables keep rows far longer than the rest on a side list (table_stats_update)       // tables whose bf16 mirror made room for rows (table_drop_mirror)
@@ -391,7 +398,8 @@ static int search_scan_path(const TableView& tv_in, const SelGeom& g, int dpad, 
             // kernels before and after a scan overlap with the scans of the other streams.
             std::unique_lock<std::mutex> chain(G.chain_mu);
             // (the no-allocation entry point creates no events: its scans are neither chained nor timed)
-            const bool ordered = G.scan_serialize != 0 && !ws.fixed;
+            // (nor are scans of a few megabytes: they come from the caches, and an event per call is most of their cost)
+            const bool ordered = G.scan_serialize != 0 && !ws.fixed && (double)tsc.n * tsc.m * 16.0 >= 256e6;
             if (!ordered) chain.unlock();
             if (ordered) {
                 if (G.chain_head >= 0 && G.chain_last != st)
@@ -411,7 +419,8 @@ static int search_scan_path(const TableView& tv_in, const SelGeom& g, int dpad, 
         }
         VDB_HIP(launch_finalize(tv, qprep, qinfo, nqi, dpad, gs, Gx1 * gs.W, k, cs, ct, (const float*)ws.cand_h.p,
                                 out_ids + (size_t)q0 * k, out_scores + (size_t)q0 * k, out_counts + q0,
-                                ne, G.d_counters, fb, nullptr, st));
+                                ne, G.d_counters, fb, nullptr, st, mirror ? nullptr : ws.host_flag));
+        if (!mirror && ws.host_flag) ws.host_flag_used = true;
         int* flagged = ne;
         if (mirror && G.mirror_tier2) {
             // second tier: the queries the mirror could not certify are scanned again over the fp32 rows (a
@@ -996,6 +1005,7 @@ int vdb_set_option(const char* key, double value) {
     else if (k == "scan_serialize") { std::lock_guard<std::mutex> cl(G.chain_mu); G.scan_serialize = value != 0; }
     else if (k == "scan_sample") G.tune_sample = (int)value;     // 0 off, 1 rows up to 1024 bytes, larger: that many bytes
     else if (k == "coalesce_host") G.coalesce_host = value != 0;
+    else if (k == "host_direct") G.host_direct = value != 0;
     else if (k == "gemm_path") G.tune_gemm = value != 0;
     else if (k == "gemm_split_f16") G.tune_split_f16 = value != 0;
     else if (k == "gemm32_split") G.tune_gemm32s = value < 0 ? 0 : value > 2 ? 2 : (int)value;
@@ -1792,25 +1802,29 @@ static void search_host_batch(std::vector<HostReq*>& batch) {
     // up to 256 queries (one chunk of the scan path): the lists of flagged queries ride behind the results
     const size_t nbytes = nq <= 256 ? round_up((size_t)(2 * nq + 2) * sizeof(int), 16) : 0;
     const size_t obytes = round_up(rbytes, 16) + nbytes;
-    const bool pinned = qbytes + obytes <= ((size_t)64 << 20);
+    const size_t qspan = round_up(qbytes, 16);               // the answers start on a 16-byte boundary of the pinned block
+    const bool pinned = qspan + obytes <= ((size_t)64 << 20);
     do {
         if ((rc = ensure(ws->q_raw, qbytes, ws->last_stream))) break;
         if ((rc = ensure(ws->o_ids, obytes, ws->last_stream))) break;
         char* o_dev = (char*)ws->o_ids.p;
-        if (pinned && ws->h_cap < qbytes + obytes) {
-            if (ws->h_pin) { (void)hipStreamSynchronize(st); (void)hipHostFree(ws->h_pin); ws->h_pin = nullptr; ws->h_cap = 0; }
-            size_t want = (qbytes + obytes) * 2;
+        if (pinned && ws->h_cap < qspan + obytes) {
+            if (ws->h_pin) { (void)hipStreamSynchronize(st); (void)hipHostFree(ws->h_pin); ws->h_pin = nullptr; ws->d_pin = nullptr; ws->h_cap = 0; }
+            size_t want = (qspan + obytes) * 2;
             if (want < 65536) want = 65536;
-            if (hipHostMalloc(&ws->h_pin, want, hipHostMallocDefault) != hipSuccess) { rc = fail(VDB_ENOMEM, "pinned staging buffer"); break; }
+            if (hipHostMalloc(&ws->h_pin, want, hipHostMallocMapped) != hipSuccess) { ws->h_pin = nullptr; rc = fail(VDB_ENOMEM, "pinned staging buffer"); break; }
+            if (hipHostGetDevicePointer((void**)&ws->d_pin, ws->h_pin, 0) != hipSuccess) ws->d_pin = nullptr;
             ws->h_cap = want;
         }
+        // a few queries: no copies, the kernels work on the pinned block itself
+        const bool direct = pinned && nbytes > 0 && nq <= 4 && qbytes <= 16384 && ws->d_pin != nullptr && G.host_direct != 0;
         char* hq = pinned ? (char*)ws->h_pin : nullptr;
-        char* ho = pinned ? hq + qbytes : nullptr;
+        char* ho = pinned ? hq + qspan : nullptr;
         hipError_t e = hipSuccess;
         if (pinned) {
             size_t off = 0;
             for (HostReq* r : batch) { std::memcpy(hq + off, r->queries, (size_t)r->nq * d * sizeof(float)); off += (size_t)r->nq * d * sizeof(float); }
-            e = hipMemcpyAsync(ws->q_raw.p, hq, qbytes, hipMemcpyHostToDevice, st);
+            if (!direct) e = hipMemcpyAsync(ws->q_raw.p, hq, qbytes, hipMemcpyHostToDevice, st);
         } else {
             size_t off = 0;
             for (HostReq* r : batch) {
@@ -1825,11 +1839,54 @@ static void search_host_batch(std::vector<HostReq*>& batch) {
             ws->ne_ext = defer ? (int*)(o_dev + round_up(rbytes, 16)) : nullptr;
             ws->defer_exact = defer;
             ws->deferred.pending = false;
+            int* hflag = direct ? (int*)(ho + round_up(rbytes, 16)) : nullptr;          // direct: one word per query, set by the finalize step
+            if (direct) {
+                for (int64_t i = 0; i < nq; ++i) hflag[i] = 0;
+                ws->host_flag = (int*)(ws->d_pin + qspan + round_up(rbytes, 16));
+            }
+            char* const o_use = direct ? ws->d_pin + qspan : o_dev;
             if (tab.dropped) rc = fail(VDB_ENOTFOUND, "table was dropped");
-            else rc = search_core(tab, nq, (const float*)ws->q_raw.p, k, (long long*)o_dev,
-                                  (float*)(o_dev + ib), (int*)(o_dev + ib + sb), st, *ws);
+            else rc = search_core(tab, nq, direct ? (const float*)ws->d_pin : (const float*)ws->q_raw.p, k, (long long*)o_use,
+                                  (float*)(o_use + ib), (int*)(o_use + ib + sb), st, *ws);
             ws->defer_exact = false;
-            if (rc == VDB_OK && defer && ws->deferred.pending) {
+            ws->host_flag = nullptr;
+            const bool flags = ws->host_flag_used;
+            ws->host_flag_used = false;
+            if (rc == VDB_OK && direct) {
+                // The answers are in the pinned block when every query's word is set (1: final, 2: the exact pass is
+                // still to come).  Over a table of a few megabytes the caller watches the words instead of waiting for
+                // the stream: the kernel's last store reaches the host about 5 us before hipStreamSynchronize returns,
+                // a tenth of such a call.  Not for long: after 200 us it waits for the stream like any other call.
+                bool seen = false;
+                if (flags && (double)tab.rows.load(std::memory_order_relaxed) * tab.m * 16.0 < 256e6) {
+                    const auto t0 = std::chrono::steady_clock::now();
+                    for (unsigned it = 1; !seen; ++it) {
+                        bool all = true;
+                        for (int64_t i = 0; i < nq; ++i) all = all && *(volatile int*)&hflag[i] != 0;
+                        if (all) { seen = true; break; }
+                        if ((it & 255u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) break;
+                    }
+                    std::atomic_thread_fence(std::memory_order_acquire);
+                }
+                if (!seen) e = hipStreamSynchronize(st);
+                if (e == hipSuccess && ws->deferred.pending) {
+                    bool any = false;
+                    if (flags) {
+                        for (int64_t i = 0; i < nq; ++i) any = any || hflag[i] == 2;
+                    } else {
+                        int cnt = 0;
+                        e = hipMemcpy(&cnt, ws->deferred.flagged, sizeof(int), hipMemcpyDeviceToHost);
+                        any = cnt > 0;
+                    }
+                    if (e == hipSuccess && any) {
+                        const Workspace::Deferred& df = ws->deferred;
+                        e = launch_exact(df.tv, df.qprep, df.nq, df.dpad, df.g, df.Gxe, df.k, df.cs, df.ct, df.out_ids, df.out_scores,
+                                         df.out_counts, df.flagged, G.d_counters, st);
+                        if (e == hipSuccess) e = hipStreamSynchronize(st);
+                    }
+                }
+                if (e != hipSuccess) rc = fail(VDB_EHIP, std::string("search: ") + hipGetErrorString(e));
+            } else if (rc == VDB_OK && defer && ws->deferred.pending) {
                 // results and the list of flagged queries in one copy; the exact pass only if the list holds a query
                 e = hipMemcpyAsync(ho, o_dev, obytes, hipMemcpyDeviceToHost, st);
                 if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -1870,7 +1927,7 @@ static void search_host_batch(std::vector<HostReq*>& batch) {
             }
         }
     } while (0);
-    ws->ne_ext = nullptr; ws->defer_exact = false; ws->deferred.pending = false;
+    ws->ne_ext = nullptr; ws->defer_exact = false; ws->deferred.pending = false; ws->host_flag = nullptr; ws->host_flag_used = false;
     release_ws(ws, st);
     for (HostReq* r : batch) { r->rc = rc; if (rc != VDB_OK) r->err = tl_error; }
 }

@@ -128,7 +128,8 @@ hipError_t launch_finalize(const TableView& t, const float* qprep, const QInfo* 
                            int dpad, const SelGeom& g, int G, int k,
                            const float* cand_s, const long long* cand_t, const float* cand_h,
                            long long* out_ids, float* out_scores, int* out_counts,
-                           int* need_exact, long long* counters, const FlatBound& fb, const int* only, hipStream_t st);
+                           int* need_exact, long long* counters, const FlatBound& fb, const int* only, hipStream_t st,
+                           int* host_flag = nullptr);
 
 // Same for the batched path: one unsorted candidate array of `cap` slots per query, `cnt[q]`
 // appended, every non-candidate row known to have a fast key <= tau[q].
