@@ -142,6 +142,13 @@ int vdb_table_info(const char* name, int64_t* dim, int* metric, int* dtype,
  * table then convert its fp32 rows on the fly, with the same exact answers. */
 int vdb_table_mirror_bytes(const char* name, int64_t* out_bytes);
 
+/* Number of tables created in this process so far (vdb_create_table and vdb_load_table).  It only grows.
+ * A binding that keeps the dimension of a table beside its name (to check the shape of a query block
+ * without a vdb_table_info call per search: describe_table, app.py:203-205, is what the reference asks
+ * before every lookup) forgets what it kept when this number has moved: only a creation can make a
+ * name stand for a table of another shape.  No counterpart in the reference's client. */
+int64_t vdb_tables_created(void);
+
 /* ---- append: replaces insert(table, records=[vec], ids=[id]) (app.py:315-325) ------------- */
 /* rows: [n, dim] row-major fp32 on the host; ids: [n] caller-supplied signed 64-bit ids.
  * COSINE tables normalise each row on the device while appending. */

@@ -33,6 +33,7 @@ SIGNATURES = {
     "vdb_reserve": (C.c_int, [C.c_char_p, C.c_int64]),
     "vdb_table_info": (C.c_int, [C.c_char_p, _i64p, C.POINTER(C.c_int), C.POINTER(C.c_int), _i64p, _i64p, _i64p]),
     "vdb_table_mirror_bytes": (C.c_int, [C.c_char_p, _i64p]),
+    "vdb_tables_created": (C.c_int64, []),
     "vdb_insert": (C.c_int, [C.c_char_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "vdb_insert_dev": (C.c_int, [C.c_char_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vdb_insert_synthetic": (C.c_int, [C.c_char_p, C.c_int64, C.c_uint64, C.c_int64]),

@@ -48,6 +48,7 @@ struct Workspace {
     hipStream_t last_stream = nullptr;   // stream the last call was enqueued on
     hipEvent_t  done = nullptr;          // recorded after the last call's work
     bool        used = false;
+    bool        host_idle = false;       // released by a blocking call on the workspace's own stream: no event was recorded
     bool        fixed = false;           // buffers are carved from a fixed region: never (re)allocated
     DevBuf qprep, qinfo, cand_s, cand_t, need_exact;      // search scratch
     DevBuf small;                                         // batched path: cnt | lost | thr0 | thr1
@@ -220,17 +221,22 @@ static std::shared_ptr<Table> find_table(const char* name) {
 
 // A workspace may be reused at once by work on the stream it last served (stream order keeps the
 // two uses apart); otherwise only after its last work has completed.
-static int acquire_ws(hipStream_t st, std::unique_ptr<Workspace>& out) {
+static int acquire_ws(hipStream_t st, std::unique_ptr<Workspace>& out, bool own_stream = false) {
     {
         std::lock_guard<std::mutex> lk(G.mu);
         int pick = -1;
         for (size_t i = 0; i < G.free_ws.size(); ++i) {
             Workspace* w = G.free_ws[i].get();
-            if (!w->used || (st != nullptr && w->last_stream == st)) { pick = (int)i; break; }
+            // unused, or last used on the stream the new work goes to (the blocking entry points work on the
+            // workspace's own stream): stream order is all the new call needs
+            if (!w->used || (st != nullptr && w->last_stream == st) || (own_stream && w->last_stream == w->stream)) { pick = (int)i; break; }
         }
         if (pick < 0) {
-            for (size_t i = 0; i < G.free_ws.size(); ++i)
-                if (hipEventQuery(G.free_ws[i]->done) == hipSuccess) { pick = (int)i; break; }
+            for (size_t i = 0; i < G.free_ws.size(); ++i) {
+                Workspace* w = G.free_ws[i].get();
+                const hipError_t q = w->host_idle ? hipStreamQuery(w->stream) : hipEventQuery(w->done);
+                if (q == hipSuccess) { pick = (int)i; break; }
+            }
         }
         if (pick >= 0) {
             out = std::move(G.free_ws[pick]);
@@ -248,7 +254,10 @@ static int acquire_ws(hipStream_t st, std::unique_ptr<Workspace>& out) {
 static void release_ws(std::unique_ptr<Workspace>& w, hipStream_t st) {
     w->used = true;
     w->last_stream = st;
-    (void)hipEventRecord(w->done, st);
+    // a blocking call has waited for its own stream (or seen its last store): no event, the stream itself says
+    // whether anything is left on it
+    w->host_idle = st == w->stream;
+    if (!w->host_idle) (void)hipEventRecord(w->done, st);
     std::lock_guard<std::mutex> lk(G.mu);
     G.free_ws.push_back(std::move(w));
 }
@@ -1128,6 +1137,8 @@ int vdb_table_info(const char* name, int64_t* dim, int* metric, int* dtype, int6
     return VDB_OK;
 }
 
+int64_t vdb_tables_created(void) { return (int64_t)G.next_gen.load() - 1; }
+
 int vdb_table_mirror_bytes(const char* name, int64_t* out_bytes) {
     if (!G.inited) return fail(VDB_ESTATE, "vdb_init has not been called");
     if (!name || !out_bytes) return fail(VDB_EINVAL, "null argument");
@@ -1787,7 +1798,7 @@ static void search_host_batch(std::vector<HostReq*>& batch) {
     for (HostReq* r : batch) nq += r->nq;
     int rc = VDB_OK;
     std::unique_ptr<Workspace> ws;
-    if ((rc = acquire_ws(nullptr, ws))) {
+    if ((rc = acquire_ws(nullptr, ws, true))) {
         for (HostReq* r : batch) { r->rc = rc; r->err = tl_error; }
         return;
     }

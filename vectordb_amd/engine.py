@@ -19,6 +19,9 @@ from .config import EngineConfig
 _init_lock = threading.Lock()
 
 
+_CBuf = C.c_char * 0          # zero-length ctypes array: from_buffer(arr) passes arr's address to a pointer argument
+
+
 def _name(s: str) -> bytes:
     return s.encode("utf-8")
 
@@ -31,6 +34,8 @@ class Engine:
         with _init_lock:
             check(self.lib.vdb_init(int(device)))
         self.device = int(device)
+        self._dims = {}            # table name -> dimension (see _dim)
+        self._dims_at = -1
         self.config = config or EngineConfig()
         check(self.lib.vdb_set_option(b"use_blas_threshold", float(self.config.use_blas_threshold)))
         check(self.lib.vdb_set_option(b"cache_capacity_gb", float(self.config.cache_capacity_gb)))
@@ -125,20 +130,44 @@ class Engine:
         check(self.lib.vdb_load_table(_name(name), os.fsencode(path)))
 
     # ---- search
+    def _dim(self, name: str) -> int:
+        """Dimension of a table, kept beside its name until a table is created anywhere in the process
+        (vdb_tables_created): one call without arguments per search instead of a vdb_table_info."""
+        created = self.lib.vdb_tables_created()
+        if created != self._dims_at:
+            self._dims = {}
+            self._dims_at = created
+        d = self._dims.get(name)
+        if d is None:
+            d = self._dims[name] = self.table_info(name)["dim"]
+        return d
+
     def search(self, name: str, queries, k: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
         """queries [nq, d] -> (ids [nq,k] int64, scores [nq,k] fp32, counts [nq] int32)."""
         queries = np.ascontiguousarray(queries, dtype=np.float32)
         if queries.ndim == 1:
             queries = queries[None, :]
         nq = queries.shape[0]
-        info = self.table_info(name)
-        if nq and queries.shape[1] != info["dim"]:
-            raise VdbError(_lib.EINVAL, "query dimension %d does not match the table's %d" % (queries.shape[1], info["dim"]))
-        ids = np.full((nq, k), -1, dtype=np.int64)
-        scores = np.zeros((nq, k), dtype=np.float32)
-        counts = np.zeros((nq,), dtype=np.int32)
-        check(self.lib.vdb_search(_name(name), nq, queries.ctypes.data, int(k),
-                                  ids.ctypes.data, scores.ctypes.data, counts.ctypes.data))
+        dim = self._dim(name)
+        if nq and queries.shape[1] != dim:
+            raise VdbError(_lib.EINVAL, "query dimension %d does not match the table's %d" % (queries.shape[1], dim))
+        k = int(k)
+        # the library writes every entry of the three arrays (unused places: id -1, worst score, count 0)
+        ids = np.empty((nq, k), dtype=np.int64)
+        scores = np.empty((nq, k), dtype=np.float32)
+        counts = np.empty((nq,), dtype=np.int32)
+        if nq == 0 or k < 1:
+            ids.fill(-1)
+            scores.fill(0)
+            counts.fill(0)
+        # a ctypes view of an array's buffer costs a quarter of arr.ctypes.data (which builds a helper object per
+        # call); read-only query blocks cannot give one
+        try:
+            qbuf = _CBuf.from_buffer(queries)
+        except (TypeError, ValueError):
+            qbuf = queries.ctypes.data
+        check(self.lib.vdb_search(_name(name), nq, qbuf, k, _CBuf.from_buffer(ids), _CBuf.from_buffer(scores),
+                                  _CBuf.from_buffer(counts)))
         return ids, scores, counts
 
     def search_dev(self, name: str, nq: int, queries_ptr: int, k: int, out_ids_ptr: int,
