@@ -1,6 +1,8 @@
 """The multi-GPU engine client of the HTTP service (one worker process per device of
 gpu_resource_config.search_resources), here with two workers that share cuda:0: its answers equal
-the oracle's on the unsharded data, whatever way the rows were spread."""
+the oracle's on the unsharded data, whatever way the rows were spread.  The workers exchange their
+hits in one all-gather and merge them on the device (over gloo here: RCCL wants a GPU per rank), or,
+with cluster_backend "host", send them to the parent, which merges."""
 import numpy as np
 import pytest
 
@@ -13,8 +15,10 @@ from vectordb_amd.milvus import MetricType
 pytestmark = pytest.mark.gpu
 
 
-def test_two_worker_cluster_matches_the_oracle(tmp_path):
-    c = ClusterMilvus(EngineConfig(search_resources=[0, 0], primary_path=str(tmp_path)))
+@pytest.mark.parametrize("backend", ["", "host"])
+def test_two_worker_cluster_matches_the_oracle(tmp_path, backend):
+    c = ClusterMilvus(EngineConfig(search_resources=[0, 0], primary_path=str(tmp_path), cluster_backend=backend))
+    assert c._backend == (backend or "gloo")
     assert c.connect(host="127.0.0.1", port="19530").OK()
     try:
         for metric, om in ((MetricType.COSINE, O.COSINE), (MetricType.L2, O.L2)):
@@ -39,6 +43,17 @@ def test_two_worker_cluster_matches_the_oracle(tmp_path):
             for r, (wi, ws) in zip(res, want):
                 assert [x.id for x in r] == [int(i) for i in wi]
                 assert [np.float32(x.distance) for x in r] == list(ws)
+            # a search every worker refuses (wrong query length) fails as a whole and leaves the workers in step:
+            # the next one is answered
+            st, res = c.search_vectors(table_name=name, query_records=[[0.5] * (d + 1)], top_k=k)
+            assert not st.OK() and res == []
+            st, res = c.search_vectors(table_name=name, query_records=q[:1].tolist(), top_k=k)
+            assert st.OK() and [x.id for x in res[0]] == [int(i) for i in want[0][0]]
+            # a single query and a batch larger than the first one (new buffers on the workers)
+            q2 = cases.make_queries("ties", 12, 9, d, rows)
+            st, res = c.search_vectors(table_name=name, query_records=q2.tolist(), top_k=3)
+            want2 = O.search(O.prepare_store(rows, om), ids, q2, 3, om)
+            assert st.OK() and [[x.id for x in r] for r in res] == [[int(i) for i in wi] for wi, _ in want2]
             assert c.delete_table(name).OK() and c.has_table(name)[1] is False
         st, res = c.search_vectors(table_name="absent", query_records=[[0.0] * 4], top_k=3)
         assert not st.OK() and res == []

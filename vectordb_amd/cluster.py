@@ -8,12 +8,16 @@ the surface of that client (the seven calls of /root/reference/app.py plus the a
 
   * sends table lifecycle calls to every worker,
   * appends new rows to the least-filled shard (bulk inserts are split evenly),
-  * sends a search to all workers at once and merges the per-shard answers by
-    (score best first, id ascending) -- the order each shard already uses, so the merged top-k
-    equals the answer of one table holding all rows.
+  * sends a search to all workers at once; every worker searches its shard on its GPU, the workers
+    exchange their k hits per query in ONE all-gather between the GPUs (torch.distributed: RCCL over
+    xGMI; the record layout and the merge kernel of vectordb_amd/sharded.py) and merge them on the
+    device by (score best first, id ascending) -- the order each shard already uses, so the merged
+    top-k equals the answer of one table holding all rows.  Worker 0 hands the merged answer back.
 
-The collective-based variant for device-resident callers is vectordb_amd/sharded.py; this one is for
-the HTTP service, whose queries and answers live in host memory anyway.
+engine_config.cluster_backend chooses how the workers exchange their hits: "nccl" (RCCL; the default
+when every worker has a GPU of its own), "gloo" (the same collective through host memory: the default
+when workers share a GPU, which RCCL does not allow, i.e. the rehearsal on one device) or "host" (no
+process group: the parent merges the per-shard answers it receives over the pipes).
 """
 from __future__ import annotations
 
@@ -31,12 +35,104 @@ from .config import EngineConfig, load_config
 from .milvus import MetricType, QueryResult, Status
 
 
-def _worker_main(conn, device: int, cfg: EngineConfig) -> None:
+class _CollectiveSearch:
+    """Worker side of a search over all shards: local search into a record, all-gather of the records,
+    merge on the device (ShardedSearcher).  A worker whose local search fails still takes part in the
+    collective, with an empty record, and reports the failure afterwards: the other workers are never
+    left waiting."""
+
+    def __init__(self, client, device: int, rank: int, world: int):
+        import torch
+        from .sharded import ShardedSearcher
+        self._torch, self._make = torch, ShardedSearcher
+        self.client, self.rank, self.world = client, rank, world
+        self.dev = torch.device("cuda", device)
+        self.searchers: Dict[Tuple[int, int], Any] = {}
+        self.table, self.metric, self.err = "", 0, None
+
+    def _searcher(self, nq: int, k: int):
+        s = self.searchers.get((nq, k))
+        if s is None:
+            if len(self.searchers) >= 32:           # callers merged in front of the workers come in many sizes
+                self.searchers.clear()
+            eng = self.client._eng()
+
+            def local_search(queries, rec) -> None:
+                st = self._torch.cuda.current_stream().cuda_stream
+                try:
+                    eng.search_dev(self.table, nq, queries.data_ptr(), k, rec.ids.data_ptr(), rec.scores.data_ptr(),
+                                   rec.counts.data_ptr(), st)
+                except Exception as exc:
+                    self.err = exc
+                    rec.counts.zero_()
+
+            def merge(gathered, world, out) -> None:
+                st = self._torch.cuda.current_stream().cuda_stream
+                eng.merge_records_dev(world, nq, k, self.metric, gathered.data_ptr(), out.ids.data_ptr(),
+                                      out.scores.data_ptr(), out.counts.data_ptr(), st)
+
+            s = self.searchers[(nq, k)] = self._make(nq, k, self.dev, local_search, merge)
+        return s
+
+    def search(self, name: str, q: np.ndarray, k: int):
+        """-> (code, message, ids, scores, counts); the arrays only on worker 0."""
+        torch = self._torch
+        eng = self.client._eng()
+        nq = int(q.shape[0])
+        self.err = None
+        try:
+            info = eng.table_info(name)
+            self.table, self.metric = name, int(info["metric"])
+            if nq and q.shape[1] != info["dim"]:
+                raise _lib.VdbError(_lib.EINVAL, "query dimension %d does not match the table's %d" % (q.shape[1], info["dim"]))
+        except Exception as exc:
+            self.err = exc
+        with torch.cuda.device(self.dev):
+            qd = torch.from_numpy(np.ascontiguousarray(q, dtype=np.float32)).to(self.dev)
+            s = self._searcher(nq, k)
+            if self.err is not None:
+                # no table to search here: an empty record, so that the collective below still has every worker in it
+                s.rec_views.counts.zero_()
+                saved, s.local_search = s.local_search, (lambda queries, rec: None)
+                try:
+                    out = s.search(qd)
+                finally:
+                    s.local_search = saved
+            else:
+                out = s.search(qd)
+            if self.err is not None:
+                torch.cuda.current_stream().synchronize()
+                st = self.client._status(self.err)
+                return (st.code, st.message, None, None, None)
+            if self.rank != 0:
+                torch.cuda.current_stream().synchronize()
+                return (0, "Success", None, None, None)
+            return (0, "Success", out.ids.cpu().numpy(), out.scores.cpu().numpy(), out.counts.cpu().numpy())
+
+
+def _worker_main(conn, device: int, cfg: EngineConfig, rank: int = 0, world: int = 1, backend: str = "host",
+                 port: int = 0) -> None:
     """Runs in the worker process: one in-process client on one GPU, requests over a pipe."""
     os.environ["VDB_DEVICE"] = str(device)
+    if backend != "host" and world > 1:
+        # before the library is loaded: torch ships a HIP runtime of its own, and the one a process loads
+        # first serves both; torch finds no device behind the other one
+        import torch  # noqa: F401
     from .milvus import Milvus                      # imported here: the parent never loads the library
     client = Milvus(cfg)
     status = client.connect()
+    collective = None
+    if status.OK() and backend != "host" and world > 1:
+        try:
+            import datetime
+            import torch.distributed as dist
+            torch.cuda.set_device(device)
+            os.environ["MASTER_ADDR"] = "127.0.0.1"
+            os.environ["MASTER_PORT"] = str(port)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+            collective = _CollectiveSearch(client, device, rank, world)
+        except Exception as exc:
+            status = Status(_lib.ESTATE, "process group (%s) of the engine workers: %s: %s" % (backend, type(exc).__name__, exc))
     conn.send((status.code, status.message))
     if not status.OK():
         return
@@ -49,6 +145,13 @@ def _worker_main(conn, device: int, cfg: EngineConfig) -> None:
             break
         method, args, kwargs = msg
         try:
+            if method == "search_collective":
+                name, q, k = args
+                try:
+                    conn.send(collective.search(name, q, int(k)))
+                except Exception as exc:
+                    conn.send((_lib.EHIP, "%s: %s" % (type(exc).__name__, exc), None, None, None))
+                continue
             if method == "search_arrays":
                 # search without building result objects: (code, message, ids, scores, counts)
                 name, q, k = args
@@ -66,6 +169,19 @@ def _worker_main(conn, device: int, cfg: EngineConfig) -> None:
                 conn.send((out.code, out.message))
         except Exception as exc:
             conn.send((_lib.EINVAL, "%s: %s" % (type(exc).__name__, exc)))
+    if collective is not None:
+        try:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        except Exception:
+            pass
+
+
+def _free_port() -> int:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return int(sk.getsockname()[1])
 
 
 class ClusterMilvus:
@@ -77,6 +193,13 @@ class ClusterMilvus:
         self._metric: Dict[str, int] = {}
         self._rows: Dict[str, List[int]] = {}                # rows per shard, for least-filled placement
         self._coalescer = SearchCoalescer(self._search_arrays) if self._config.coalesce_searches else None
+        # how the workers exchange their hits (module docstring); RCCL wants one GPU per rank
+        backend = os.environ.get("VDB_CLUSTER_BACKEND") or self._config.cluster_backend
+        if not backend:
+            backend = "nccl" if len(set(self._devices)) == len(self._devices) else "gloo"
+        if backend not in ("nccl", "gloo", "host"):
+            raise ValueError("engine_config.cluster_backend must be nccl, gloo or host: %r" % (backend,))
+        self._backend = backend if len(self._devices) > 1 else "host"
 
     # -- plumbing ---------------------------------------------------------------------------
     @staticmethod
@@ -110,11 +233,13 @@ class ClusterMilvus:
             if not self._devices:
                 return Status(_lib.EINVAL, "no devices in gpu_resource_config.search_resources")
             ctx = mp.get_context("spawn")                    # never fork a process that may hold a GPU context
+            port = _free_port() if self._backend != "host" else 0
             for shard, dev in enumerate(self._devices):
                 parent, child = ctx.Pipe()
                 # every shard keeps its snapshots in a directory of its own under primary_path
                 cfg = dataclasses.replace(self._config, primary_path=os.path.join(self._config.primary_path, "shard%d" % shard))
-                proc = ctx.Process(target=_worker_main, args=(child, dev, cfg), daemon=True)
+                proc = ctx.Process(target=_worker_main, args=(child, dev, cfg, shard, len(self._devices), self._backend, port),
+                                   daemon=True)
                 proc.start()
                 child.close()
                 self._workers.append((proc, parent))
@@ -255,11 +380,18 @@ class ClusterMilvus:
 
     # -- search ----------------------------------------------------------------------------
     def _search_arrays(self, table_name: str, q: np.ndarray, k: int):
-        """All shards at once, merged on the host: (ids [nq, k], scores [nq, k], counts [nq])."""
+        """All shards at once: (ids [nq, k], scores [nq, k], counts [nq]), merged by the workers on their GPUs
+        after one all-gather, or (cluster_backend "host") here from the per-shard answers."""
         with self._lock:
             bad = self._need() or self._table_state(table_name)
             if bad:
                 raise _lib.VdbError(bad.code, bad.message)
+            if self._backend != "host" and q.shape[0] > 0:
+                replies = self._call_all("search_collective", table_name, q, k)
+                st = self._first_failure(replies)
+                if not st.OK():
+                    raise _lib.VdbError(st.code, st.message)
+                return replies[0][2], replies[0][3], replies[0][4]
             replies = self._call_all("search_arrays", table_name, q, k)
             st = self._first_failure(replies)
             if not st.OK():

@@ -22,6 +22,10 @@ in `raw` so that an existing file loads unchanged.
       db_config.primary_path whenever this many rows have arrived since its last snapshot; the write is
       incremental (only the new rows).  The engine the reference talks to persists every insert by itself,
       and /insert relies on it: a hash the relational side knows is never sent to the engine again
+  engine_config.cluster_backend (an addition, default chosen by the device list)  with more than one entry in
+      search_resources: how the worker processes exchange their hits of a search -- "nccl" (one RCCL
+      all-gather between the GPUs, merge on the device), "gloo" (the same through host memory; for workers that
+      share a GPU) or "host" (the serving process merges what the workers send it)
   gpu_resource_config.enable (:41)           must be true: there is no CPU engine
   gpu_resource_config.cache_capacity (:42)   GB of HBM the tables may occupy (0 = no cap)
   gpu_resource_config.search_resources (:43-44)  `gpuN` entries: the shard set; a process binds
@@ -50,6 +54,7 @@ class EngineConfig:
     scan_mirror: bool = False
     bf16_mirror: bool = True
     snapshot_every_rows: int = 0
+    cluster_backend: str = ""            # "" = nccl when every worker has its own GPU, else gloo; or nccl / gloo / host
     gpu_enable: bool = True
     cache_capacity_gb: float = 0.0
     search_resources: List[int] = field(default_factory=lambda: [0])
@@ -92,6 +97,8 @@ def parse_config(doc: Optional[Dict[str, Any]]) -> EngineConfig:
         cfg.bf16_mirror = bool(eng["bf16_mirror"])
     if "snapshot_every_rows" in eng and eng["snapshot_every_rows"] is not None:
         cfg.snapshot_every_rows = max(0, int(eng["snapshot_every_rows"]))
+    if eng.get("cluster_backend"):
+        cfg.cluster_backend = str(eng["cluster_backend"]).strip().lower()
     if "enable" in gpu:
         cfg.gpu_enable = bool(gpu["enable"])
     if "cache_capacity" in gpu and gpu["cache_capacity"] is not None:
