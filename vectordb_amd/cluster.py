@@ -114,6 +114,7 @@ def _worker_main(conn, device: int, cfg: EngineConfig, rank: int = 0, world: int
                  port: int = 0) -> None:
     """Runs in the worker process: one in-process client on one GPU, requests over a pipe."""
     os.environ["VDB_DEVICE"] = str(device)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # RCCL's IPC handles need the dmabuf path on this driver
     if backend != "host" and world > 1:
         # before the library is loaded: torch ships a HIP runtime of its own, and the one a process loads
         # first serves both; torch finds no device behind the other one
