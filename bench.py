@@ -471,8 +471,21 @@ def rank_main(args, world: int) -> None:
             from tools.bench_http import run as http_run
             with contextlib.redirect_stdout(sys.stderr):            # the routes print like the reference's do
                 h = http_run(10_000, 384, 100)
+            # the engine part of such a lookup: blocking vdb_search calls of one query from host memory
+            eng.create_table("bench_small", 384, METRICS["cosine"], DTYPES["f32"][0])
+            eng.insert_synthetic("bench_small", 10_000, seed=0, first_row=0)
+            sq = np.random.default_rng(1).random((450, 384)).astype(np.float32)
+            call_us = []
+            for i in range(450):
+                t0 = time.perf_counter()
+                eng.search("bench_small", sq[i:i + 1], 10)
+                if i >= 50:
+                    call_us.append((time.perf_counter() - t0) * 1e6)
+            eng.drop_table("bench_small")
             secondary.append({"metric": "PUT /lookup per second, 10000x384 f32 cosine top-10 through the HTTP routes",
                               "value": h["lookup_qps"], "unit": "QPS", "lookup_ms": h["lookup_ms"],
+                              "engine_call_us": {"p50": float(np.percentile(call_us, 50)), "p99": float(np.percentile(call_us, 99)),
+                                                 "calls": len(call_us), "what": "blocking vdb_search of one query over the same 10000x384 table, through the Python binding"},
                               "insert_rows_per_s": h["insert_rows_per_s"], "workload": h["workload"], "dtype": "f32",
                               "note": "BASELINE configuration 1 (the reference's own workload shape) end to end; no roofline: a call is all fixed cost"})
         except Exception as exc:        # the HTTP layer needs flask; the kernels' numbers do not depend on it

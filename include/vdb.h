@@ -113,7 +113,10 @@ int vdb_shutdown(void);
  * "force_exact" (1 = every query is answered by the exact pass; for measuring it).
  * Host calls: "coalesce_host" (1 = blocking vdb_search calls that arrive from other threads while one
  * is running are merged into one batched search, see vdb_search, and vdb_insert calls of up to 256 rows
- * into one append; default 1). */
+ * into one append; default 1), "host_direct" (1 = blocking vdb_search calls of up to four queries leave out both
+ * copies: the kernels read the queries from the library's pinned host block and write the answers into it, and over
+ * tables under 256 MB the caller watches one word per query there instead of waiting for the stream, for at most
+ * 200 us; default 1; 0 = copy in, copy out, wait for the stream). */
 int vdb_set_option(const char* key, double value);
 const char* vdb_last_error(void);
 
