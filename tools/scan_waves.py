@@ -23,7 +23,7 @@ lib.vdb_debug_scan_waves(ends, xcc, n)
 e = [ends[i] / 100.0 for i in range(n)]
 x = [xcc[i] & 0xf for i in range(n)]
 hw = [xcc[i] >> 4 for i in range(n)]
-print("all waves: min %.0f median %.0f max %.0f us" % (min(e), st.median(e), max(e)))
+print("all waves: min %.1f median %.1f max %.1f us" % (min(e), st.median(e), max(e)))
 by = collections.defaultdict(list)
 for i in range(n): by[x[i]].append(e[i])
 for k in sorted(by): print("xcc %d: %4d waves, min %.0f median %.0f max %.0f" % (k, len(by[k]), min(by[k]), st.median(by[k]), max(by[k])))
