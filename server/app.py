@@ -224,8 +224,9 @@ def create_app(client: Milvus = None, store: MetaStore = None, compat_lookup: bo
         exact = store_().assets(name, hash_vector(vector))
         results = [{"distance": 0, "asset_ids": exact}]
         for hit in hits:
-            assets = store_().assets(name, hit["vectorhash"])
-            results.append({"distance": hit["distance"], "asset_ids": exact if compat_bug else assets})
+            # (the reference looks every hit's assets up as well and then returns the exact match's: app.py:431)
+            assets = exact if compat_bug else store_().assets(name, hit["vectorhash"])
+            results.append({"distance": hit["distance"], "asset_ids": assets})
         return results
 
     @app.route("/lookup", methods=["PUT"])

@@ -5,6 +5,15 @@ import hashlib
 from typing import Iterable
 
 
+_FORMATS = {}     # length -> "%.5f,%.5f,...": one format operation per vector instead of one per component
+
+
 def hash_vector(vector: Iterable[float]) -> int:
-    text = ",".join("%.5f" % component for component in vector)
+    values = tuple(vector)
+    fmt = _FORMATS.get(len(values))
+    if fmt is None:
+        if len(_FORMATS) > 64:
+            _FORMATS.clear()
+        fmt = _FORMATS[len(values)] = ",".join(["%.5f"] * len(values))
+    text = fmt % values
     return int.from_bytes(hashlib.md5(text.encode("utf-8")).digest()[:8], "little", signed=True)
