@@ -19,7 +19,7 @@ def test_hash_vector_matches_reference_golden():
     assert len(golden) >= 5
     for g in golden:
         assert O.hash_vector(g["vector"]) == g["hash"]
-    # survey-recorded known answers of app.py:328-334
+    # known answers of app.py:328-334 for three fixed inputs (computed from its definition by hand: md5 of the text form)
     assert O.hash_vector([0.0] * 8) == 8770679782603771991
     assert O.hash_vector([1.0, 2.0, 3.0, 4.0]) == -232953353825745962
     assert O.hash_vector([]) == 338333539836370388
