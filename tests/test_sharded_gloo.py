@@ -1,4 +1,4 @@
-"""Multi-process test of the row-sharded search on CPU (gloo, world size 2): partitioning, the
+"""Multi-process test of the row-sharded search on CPU (gloo, world sizes 2 and 3): partitioning, the
 per-rank record layout, the single all-gather and the merge call pattern of
 vectordb_amd/sharded.py.  The two compute steps are the injection points of ShardedSearcher; here
 they are stood in by the oracle (the product's `gpu_backend` needs a GPU and is covered by the
@@ -74,9 +74,9 @@ def _worker(rank, world, port, metric_name, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("metric", ["ip", "l2"])
-def test_sharded_search_gloo_world2(metric):
-    world = 2
+@pytest.mark.parametrize("metric,world", [("ip", 2), ("l2", 2), ("ip", 3)])
+def test_sharded_search_gloo(metric, world):
+    # (three ranks: shards of unequal length, 334 + 334 + 335 rows)
     port = _free_port()
     ctx = mp.get_context("spawn")
     with ctx.Manager() as mgr:
@@ -88,7 +88,7 @@ def test_sharded_search_gloo_world2(metric):
             p.join(timeout=180)
         for p in procs:
             assert p.exitcode == 0, "rank exited with %s" % p.exitcode
-        assert dict(ret) == {0: True, 1: True}
+        assert dict(ret) == {r: True for r in range(world)}
 
 
 def test_shard_ranges_cover_rows_exactly():
