@@ -28,16 +28,13 @@ ls, mg = gpu_backend(eng, "r", 1, 10, _lib.METRIC_COSINE)
 streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
 searchers = [ShardedSearcher(1, 10, dev, ls, mg) for _ in range(3)]
 for s in searchers:
-    s.world = 1
+    s.force_collective = True            # the collective and the merge although the world has one rank
 torch.cuda.synchronize()
 outs = []
 for i in range(8):
     with torch.cuda.stream(streams[i % 3]):
-        s = searchers[i % 3]
-        s.local_search(q[i:i + 1], s.rec_views)
-        dist.all_gather_into_tensor(s.gathered, s.rec)              # the collective bench.py issues for N > 1
-        s.merge(s.gathered, 1, s.out_views)
-        outs.append((s.out_views.ids.clone(), s.out_views.scores.clone()))
+        out = searchers[i % 3].search(q[i:i + 1])                   # what bench.py calls per step for N > 1
+        outs.append((out.ids.clone(), out.scores.clone()))
 torch.cuda.synchronize()
 dist.barrier()
 ids, sc, cnt = eng.search("r", q.cpu().numpy(), 10)
