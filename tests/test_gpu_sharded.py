@@ -108,3 +108,23 @@ def test_bench_with_two_ranks_answers_like_one():
     for part in ("host_enqueue_us", "device_complete_us"):
         assert set(tr[part]) >= {"local_search", "collective", "merge"} and tr[part]["steps"] >= 4
     assert tr["device_complete_us"]["local_search"] > 0 and tr["device_complete_us"]["collective"] > 0
+
+
+def test_rccl_path_with_a_world_of_one_rank():
+    """The calls an N-rank run makes, through the real RCCL backend with the one rank a one-GPU box allows:
+    process group with a device id, ShardedSearcher.search on three streams (local search, the all-gather
+    issued from the process's collective stream, merge), teardown; the answers are those of a plain
+    search (tools/rccl_single_rank_check.py, run as a child process with a port of its own)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    for var in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(var, None)
+    env.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_single_rank_check.py")], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert res.returncode == 0, (res.stdout[-1000:], res.stderr[-2000:])
+    assert "RCCL single-rank path: ok" in res.stdout
