@@ -482,10 +482,26 @@ def rank_main(args, world: int) -> None:
                 if i >= 50:
                     call_us.append((time.perf_counter() - t0) * 1e6)
             eng.drop_table("bench_small")
+            # the same engine call on the host cores: the oracle's BLAS path over 10 000 x 384 U[0,1) rows (checker
+            # code, timed as the CPU baseline of this configuration; it is not part of any product path)
+            cpu_small = None
+            if args.cpu_seconds > 0:
+                from oracle import oracle as O
+                cx = O.prepare_store(np.random.default_rng(0).random((10_000, 384)), O.COSINE, O.F32)
+                cids = np.arange(10_000, dtype=np.int64)
+                O.fast_search(cx, cids, sq[:1], 10, O.COSINE)
+                cpu_us = []
+                for i in range(200):
+                    t0 = time.perf_counter()
+                    O.fast_search(cx, cids, sq[i:i + 1], 10, O.COSINE)
+                    cpu_us.append((time.perf_counter() - t0) * 1e6)
+                cpu_small = {"p50": float(np.percentile(cpu_us, 50)), "p99": float(np.percentile(cpu_us, 99)), "calls": len(cpu_us),
+                             "kind": "port", "what": "oracle.fast_search (numpy sgemv + argpartition + fp64 re-score) of one query over 10000x384 on the host cores"}
             secondary.append({"metric": "PUT /lookup per second, 10000x384 f32 cosine top-10 through the HTTP routes",
                               "value": h["lookup_qps"], "unit": "QPS", "lookup_ms": h["lookup_ms"],
                               "engine_call_us": {"p50": float(np.percentile(call_us, 50)), "p99": float(np.percentile(call_us, 99)),
                                                  "calls": len(call_us), "what": "blocking vdb_search of one query over the same 10000x384 table, through the Python binding"},
+                              "cpu_engine_call_us": cpu_small,
                               "insert_rows_per_s": h["insert_rows_per_s"], "workload": h["workload"], "dtype": "f32",
                               "note": "BASELINE configuration 1 (the reference's own workload shape) end to end; no roofline: a call is all fixed cost"})
         except Exception as exc:        # the HTTP layer needs flask; the kernels' numbers do not depend on it
