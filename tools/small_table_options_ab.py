@@ -19,7 +19,7 @@ def run(label):
         lat.append((time.perf_counter() - t) * 1e6)
     print("%-28s p50 %.1f us  p10 %.1f  p90 %.1f" % (label, np.percentile(lat, 50), np.percentile(lat, 10), np.percentile(lat, 90)), flush=True)
 run("defaults")
-for key, vals, default in (("scan_waves", (4, 16), 8), ("scan_dynamic", (0,), 1), ("scan_nt", (0,), 1), ("scan_contiguous", (0,), 1), ("scan_blocks_per_cu", (1, 2), 4)):
+for key, vals, default in (("fin_threads", (1024, 256), 512), ("scan_waves", (4, 16), 8), ("scan_dynamic", (0,), 1), ("scan_nt", (0,), 1), ("scan_contiguous", (0,), 1), ("scan_blocks_per_cu", (1, 2), 4)):
     for v in vals:
         eng.set_option(key, v)
         run("%s=%s" % (key, v))

@@ -1289,8 +1289,16 @@ RowBound l2_row_bound(const FlatBound& fb, int d, const QInfo* qinfo, int nq) {
 // list takes part with its p-th entry, p in {1, 2, 4, 8, 16} chosen for the fewest expected survivors: with rows
 // dealt to the G lists at random, a list holds Poisson(lambda) rows above a value that N = lambda * G rows reach,
 // and the bound is the value that ceil(K / p) of the G lists reach with p rows.
-static int fin_pth(int G, int K) {
-    const int nth = 1024;
+static int g_fin_threads = 512;        // measured on the blocking path over small tables: 1024 threads 41.7 us per call, 512 39.5, 256 41.3
+void set_fin_threads(int v) { g_fin_threads = (v == 256 || v == 512) ? v : 1024; }
+// threads of the lists-mode finalize launch: the option's, as long as every thread owns at most eight lists
+static int fin_threads(int G) {
+    int nth = g_fin_threads;
+    while (nth < 1024 && (long long)G > 8LL * nth) nth <<= 1;
+    return nth;
+}
+
+static int fin_pth(int G, int K, int nth) {
     if (G > 8 * nth) return 0;                           // the kernel ranks the heads from memory
     const int lpt = (G + nth - 1) / nth;
     if ((G + lpt - 1) / lpt >= 2 * K) return 0;
@@ -1327,13 +1335,14 @@ hipError_t launch_finalize(const TableView& t, const float* qprep, const QInfo* 
     p.need_exact = need_exact; p.counters = counters;
     p.flat_cnt = nullptr; p.flat_cap = 0; p.flat_tau = nullptr; p.flat_lost = nullptr; p.flat_bad = nullptr;
     p.dd_mult = fb.dd_mult; p.extra_rel = fb.extra_rel; p.extra_abs = fb.extra_abs; p.l2_bias = 0.0; p.force_exact = fb.force_exact; p.floor_out = nullptr;
-    p.pth = fin_pth(G, g.K);
+    const int nth = fin_threads(G);
+    p.pth = fin_pth(G, g.K, nth);
     int kr = 1; while (kr < g.K) kr <<= 1;
     p.fin_cap = g.K > 512 ? FIN_CAP_LONG : FIN_CAP;
     const size_t lds = 1088 + (size_t)g.K * 12 + (size_t)kr * 12 + (size_t)p.fin_cap * 8;
     hipError_t e = allow_lds(finalize_kernel, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)nq), dim3(1024), lds, st, p);
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)nq), dim3((unsigned)nth), lds, st, p);
     return hipGetLastError();
 }
 
@@ -1345,13 +1354,14 @@ hipError_t launch_lists_floor(const SelGeom& g, int G, int64_t nq, const float* 
     p.K = g.K; p.C = g.C; p.G = G; p.k = 1;
     p.cand_s = cand_s; p.cand_t = cand_t; p.cand_h = cand_h;
     p.floor_out = floor_out;
-    p.pth = fin_pth(G, g.K);
+    const int nth = fin_threads(G);
+    p.pth = fin_pth(G, g.K, nth);
     int kr = 1; while (kr < g.K) kr <<= 1;
     p.fin_cap = g.K > 512 ? FIN_CAP_LONG : FIN_CAP;
     const size_t lds = 1088 + (size_t)g.K * 12 + (size_t)kr * 12 + (size_t)p.fin_cap * 8;
     hipError_t e = allow_lds(finalize_kernel, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)nq), dim3(1024), lds, st, p);
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)nq), dim3((unsigned)nth), lds, st, p);
     return hipGetLastError();
 }
 

@@ -1015,6 +1015,7 @@ int vdb_set_option(const char* key, double value) {
     else if (k == "scan_sample") G.tune_sample = (int)value;     // 0 off, 1 rows up to 1024 bytes, larger: that many bytes
     else if (k == "coalesce_host") G.coalesce_host = value != 0;
     else if (k == "host_direct") G.host_direct = value != 0;
+    else if (k == "fin_threads") set_fin_threads((int)value);
     else if (k == "gemm_path") G.tune_gemm = value != 0;
     else if (k == "gemm_split_f16") G.tune_split_f16 = value != 0;
     else if (k == "gemm32_split") G.tune_gemm32s = value < 0 ? 0 : value > 2 ? 2 : (int)value;

@@ -95,6 +95,7 @@ struct SearchScratch {
 
 void set_scan_tune(int nt, int waves, int blocks_per_cu, int contiguous, int dynamic);
 void set_scan_short_bytes(double bytes);
+void set_fin_threads(int v);           // threads of the lists-mode finalize launch (256, 512 or 1024)
 hipError_t launch_read_bw(const void* buf, long long bytes, int nt, int blocks, int threads,
                           unsigned int* sink, hipStream_t st);
 
