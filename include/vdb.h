@@ -81,7 +81,8 @@ int vdb_shutdown(void);
  * rows of up to 4096 bytes, or of up to the value given when it is larger than 1; 0 = never);
  * "scan_dynamic" (1 = the waves of a scan workgroup draw their steps from a counter in LDS (default);
  * 0 = every wave scans a fixed share); "scan_short_gb" (tables below this many GB are scanned by one resident
- * round of workgroups whose waves advance side by side; default 28).
+ * round of workgroups whose waves advance side by side; default 28); "fin_threads" (threads of the finalize
+ * workgroup behind a scan: 512 (default), 256 or 1024; raised by itself when a thread would own more than eight lists).
  * Batched path (all its passes run on the 16-bit matrix unit; the finalize step re-scores every
  * candidate within twice the error bound of the k-th best fast key, so a coarser pass costs
  * re-scoring, never exactness): "gemm_path" (0 sends every batch through the scan path),
