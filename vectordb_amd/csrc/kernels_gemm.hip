@@ -238,29 +238,63 @@ kth_threshold_kernel(const float* __restrict__ cand_s, long long stride, const i
     uint32_t prefix = 0;
     int need = K;
     bool short_list = false;
+    // Up to eight candidates per thread are read once, with unguarded loads (a guarded load becomes a branch
+    // and a wait of its own), and stay in registers for the four passes; longer arrays are re-read per pass.
+    constexpr int U = 8;
+    const bool in_regs = count <= (long long)U * nth;
+    float v[U];
+    if (in_regs) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long i = (long long)u * nth + tid;
+            const long long ic = i < count ? i : 0;
+            float x = gs[ic];
+            if (n2 != nullptr) {
+                // rows on the table's list of long rows do not take part (every query re-scores them anyway)
+                const long long r = gt ? gt[ic] : ic;
+                const bool known = r >= 0 && r < nrows;
+                const float nn = n2[known ? r : 0];
+                if (known && nn > out_limit) x = -__builtin_huge_valf();
+            }
+            v[u] = i < count ? x : -__builtin_huge_valf();
+        }
+    }
+    // one increment per distinct bin and wave for the bins many lanes share (four rounds), the LDS atomics for the rest
+    auto hist_add = [&](bool act, int bin) __attribute__((always_inline)) {
+        unsigned long long todo = __ballot(act);
+        for (int round = 0; todo && round < 4; ++round) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int b = __shfl(bin, leader);
+            const unsigned long long same = __ballot(act && bin == b) & todo;
+            if (lane == leader) atomicAdd(&hist[b], __popcll(same));
+            todo &= ~same;
+        }
+        if ((todo >> lane) & 1ull) atomicAdd(&hist[bin], 1);
+    };
     for (int pass = 0; pass < 4; ++pass) {
         if (tid < 256) hist[tid] = 0;
         __syncthreads();
         const int shift = 24 - 8 * pass;
-        for (long long i0 = 0; i0 < count; i0 += nth) {
-            const long long i = i0 + tid;
-            float v = (i < count) ? gs[i] : -__builtin_huge_valf();
-            if (n2 != nullptr && i < count) {
-                // rows on the table's list of long rows do not take part (every query re-scores them anyway)
-                const long long r = gt ? gt[i] : i;
-                if (r >= 0 && r < nrows && n2[r] > out_limit) v = -__builtin_huge_valf();
+        if (in_regs) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if ((long long)u * nth < count) {                  // block-uniform
+                    const uint32_t key = fkey_g(v[u]);
+                    const bool act = (v[u] > -__builtin_huge_valf()) && (pass == 0 || (key >> (shift + 8)) == prefix);
+                    hist_add(act, (int)((key >> shift) & 255u));
+                }
             }
-            const uint32_t key = fkey_g(v);
-            const bool act = (v > -__builtin_huge_valf()) && (pass == 0 || (key >> (shift + 8)) == prefix);
-            // aggregate equal bins of a wave into one LDS atomic
-            unsigned long long todo = __ballot(act);
-            const int bin = (int)((key >> shift) & 255u);
-            while (todo) {
-                const int leader = __ffsll((long long)todo) - 1;
-                const int b = __shfl(bin, leader);
-                const unsigned long long same = __ballot(act && bin == b) & todo;
-                if (lane == leader) atomicAdd(&hist[b], __popcll(same));
-                todo &= ~same;
+        } else {
+            for (long long i0 = 0; i0 < count; i0 += nth) {
+                const long long i = i0 + tid;
+                float x = (i < count) ? gs[i] : -__builtin_huge_valf();
+                if (n2 != nullptr && i < count) {
+                    const long long r = gt ? gt[i] : i;
+                    if (r >= 0 && r < nrows && n2[r] > out_limit) x = -__builtin_huge_valf();
+                }
+                const uint32_t key = fkey_g(x);
+                const bool act = (x > -__builtin_huge_valf()) && (pass == 0 || (key >> (shift + 8)) == prefix);
+                hist_add(act, (int)((key >> shift) & 255u));
             }
         }
         __syncthreads();
