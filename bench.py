@@ -213,9 +213,11 @@ def rank_main(args, world: int) -> None:
         local_search, merge = gpu_backend(eng, table, nq, k, metric)
         # batches keep the GPU busy on their own; single queries are pipelined over several streams
         if n_streams <= 0:
-            # queries in flight: three over a long scan; two over a scan of a few hundred microseconds, where
-            # a third queue's small kernels cost more between scans than they hide (measured: 12 us per query)
-            n_streams = 3 if (n_local * dim * esz >= 8e9 or world > 1) else 2
+            # queries in flight: two; over a scan of a few hundred microseconds a third queue's small kernels cost more
+            # between scans than they hide (measured: 12 us per query)
+            # (two also over a long scan on one GPU: the same QPS as three, and an answer after two scans instead of
+            # three; the collective of a sharded run is what the third one hides)
+            n_streams = 3 if world > 1 else 2
         n_streams = max(1, n_streams) if nq == 1 else 1
         searchers = [ShardedSearcher(nq, k, dev, local_search, merge) for _ in range(n_streams)]
         # the same stream objects for every workload of the process: the device has four hardware queues,
