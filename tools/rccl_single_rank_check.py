@@ -36,6 +36,23 @@ for i in range(8):
         out = searchers[i % 3].search(q[i:i + 1])                   # what bench.py calls per step for N > 1
         outs.append((out.ids.clone(), out.scores.clone()))
 torch.cuda.synchronize()
+# host cost of one step through the RCCL path (enqueue only, three streams in rotation): what the Python + c10d
+# layer adds per query next to a shard scan of half a millisecond
+import time
+for s_ in searchers:
+    s_.trace = []
+t0 = time.perf_counter()
+nrep = 300
+for i in range(nrep):
+    with torch.cuda.stream(streams[i % 3]):
+        searchers[i % 3].search(q[i % 8:i % 8 + 1])
+host_us = (time.perf_counter() - t0) / nrep * 1e6
+torch.cuda.synchronize()
+tr = np.array([t for s_ in searchers for t in s_.trace])
+print("host time per step: %.1f us (local search %.1f, collective %.1f, merge %.1f: medians of %d steps)"
+      % (host_us, np.median(tr[:, 0]), np.median(tr[:, 1]), np.median(tr[:, 2]), tr.shape[0]))
+for s_ in searchers:
+    s_.trace = None
 dist.barrier()
 ids, sc, cnt = eng.search("r", q.cpu().numpy(), 10)
 ok = all(np.array_equal(o[0].cpu().numpy()[0], ids[i]) and np.array_equal(o[1].cpu().numpy()[0], sc[i]) for i, o in enumerate(outs))
